@@ -1,0 +1,37 @@
+/* Constants of the gfx950 Gaussian-splat render path that are part of its CONTRACT:
+ * the CPU oracle (oracle/) and the HIP kernels (gaussian-splatting_amd/csrc/) must agree
+ * on them bit for bit, because tile rectangles, instance keys and tile ranges are compared
+ * exactly.  Plain C, no dependencies. */
+#ifndef GSX_CONSTANTS_H
+#define GSX_CONSTANTS_H
+
+/* screen tile edge in pixels; one 256-thread workgroup (4 wave64) composites one tile */
+#define GSX_TILE 16
+#define GSX_TILE_SHIFT 4
+
+/* 2D covariance regulariser: reference adds 1e-6*I before inversion
+ * (/root/reference/model/gaussian_splatting.py:128-130) */
+#define GSX_COV_EPS 1e-6f
+
+/* footprint cut: a (pixel, Gaussian) pair is dropped from the tile lists only where
+ * |alpha| = |opacity| * exp(-q/2) is provably below 2^-GSX_CUT_LOG2.  The reference has no
+ * cut-off (dense evaluation, gaussian_splatting.py:118-144); 2^-24 keeps the dropped mass
+ * far below the 1e-4 RGB tolerance. */
+#define GSX_CUT_LOG2 24
+/* 2*ln(2) rounded to float: kappa^2 = GSX_TWO_LN2 * (exponent(|o|) + 1 + GSX_CUT_LOG2) */
+#define GSX_TWO_LN2 1.3862944f
+
+/* global early exit threshold (gaussian_splatting.py:147) */
+#define GSX_SAT_ALPHA 0.99f
+
+/* floats per rank-ordered splat record:
+ *  0 mu_x  1 mu_y  2 k00  3 kb   | 4 k11  5 opacity  6 r  7 g | 8 b  9 depth  10 rect_lo  11 rect_hi
+ * k00,kb,k11 = conic (M00, M01+M10, M11) pre-multiplied by -0.5*log2(e) so that
+ * alpha = opacity * exp2(k00*dx*dx + kb*dx*dy + k11*dy*dy).
+ * rect_lo / rect_hi are the bit patterns of (x0 | y0<<16) and (x1 | y1<<16), tile units, x1/y1 exclusive. */
+#define GSX_REC_FLOATS 12
+
+/* "no saturation" marker for the per-pixel saturation rank */
+#define GSX_RANK_NONE 0xFFFFFFFFu
+
+#endif

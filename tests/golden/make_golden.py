@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference renderer.
+
+Runs only in the build container (needs /root/reference); the GPU box never runs
+this script -- it only reads the .npz files it wrote.  Nothing from the reference
+is copied: the reference module is imported from where it lies, executed on seeded
+inputs, and its inputs/outputs/gradients are stored as plain arrays.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Every fixture holds
+    params   positions scales rotations opacity features      (the five nn.Parameters)
+    poses (B,4,4), H, W
+    outputs  rendered_images positions2d depths cov2d           (forward dict)
+    order    argsort(depths[0], descending)                     (gaussian_splatting.py:198,206)
+    n_composited   number of Gaussians composited before the global early exit
+                   (= number of torch.all calls in _render_chunk, gaussian_splatting.py:147)
+    upstream d_rgb d_pos2d d_depths d_cov2d and the five parameter gradients of
+             L = sum(out*upstream) over the four differentiable outputs.
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+REF = os.environ.get("GSX_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+from model.gaussian_splatting import GaussianSplat  # noqa: E402  (the reference itself)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def scene_default(n, seed):
+    """The reference's own init (gaussian_splatting.py:37-63) under manual_seed."""
+    torch.manual_seed(seed)
+    return GaussianSplat(n, chunk_size=10)
+
+
+def scene_synth(n, seed, s_lo, s_hi, o_lo=0.0, o_hi=1.0, zq=None):
+    """SURVEY 8d synthetic distribution (c2..c5 style), written into a reference module."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    m = GaussianSplat(n, chunk_size=10)
+    with torch.no_grad():
+        p = torch.empty(n, 3)
+        p[:, :2] = torch.rand(n, 2, generator=g) * 2 - 1
+        p[:, 2] = torch.rand(n, generator=g) + 0.5
+        if zq is not None:
+            p[:, 2] = torch.round(p[:, 2] * zq) / zq
+        m.positions.copy_(p)
+        m.scales.copy_(torch.exp(torch.rand(n, 3, generator=g) * (np.log(s_hi) - np.log(s_lo)) + np.log(s_lo)))
+        q = torch.randn(n, 4, generator=g)
+        m.rotations.copy_(q / q.norm(dim=1, keepdim=True))
+        m.opacity.copy_(torch.rand(n, 1, generator=g) * (o_hi - o_lo) + o_lo)
+        m.features.copy_(torch.rand(n, 3, generator=g))
+    return m
+
+
+def pose_tz(tz):
+    p = torch.eye(4)
+    p[2, 3] = tz
+    return p
+
+
+def orbit_pose(i, n_views=60, radius=4.0, elevation=45.0):
+    """Arithmetic of utils/visualization.py:156-178 evaluated with plain torch."""
+    import torch.nn.functional as F
+    angle = 2 * np.pi * i / n_views
+    x = radius * np.cos(angle) * np.cos(np.radians(elevation))
+    y = radius * np.sin(angle) * np.cos(np.radians(elevation))
+    z = radius * np.sin(np.radians(elevation))
+    pos = torch.tensor([x, y, z], dtype=torch.float32)
+    forward = F.normalize(torch.zeros(3) - pos, dim=0)
+    up = torch.tensor([0., 0., 1.])
+    right = F.normalize(torch.linalg.cross(forward, up), dim=0)
+    up = F.normalize(torch.linalg.cross(right, forward), dim=0)
+    pose = torch.eye(4)
+    pose[:3, :3] = torch.stack([right, up, -forward], dim=1)
+    pose[:3, 3] = pos
+    return pose
+
+
+def analytic_upstream(shape):
+    """Closed-form upstream gradient (no RNG) used where storing it would be too big."""
+    B, C, H, W = shape
+    b, c, y, x = np.meshgrid(np.arange(B), np.arange(C), np.arange(H), np.arange(W), indexing="ij")
+    return np.sin(0.37 * c + 0.11 * y + 0.07 * x + 0.5 * b).astype(np.float32)
+
+
+def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, analytic=False):
+    n = model.num_gaussians
+    B = poses.shape[0]
+    # count the early-exit tests the reference performs
+    calls = {"n": 0}
+    real_all = torch.all
+
+    def counting_all(*a, **k):
+        calls["n"] += 1
+        return real_all(*a, **k)
+
+    torch.all = counting_all
+    try:
+        out = model(poses, (H, W))
+    finally:
+        torch.all = real_all
+    g = torch.Generator(device="cpu").manual_seed(seed_up)
+    if analytic:
+        d_rgb = torch.from_numpy(analytic_upstream((B, 3, H, W)))
+    else:
+        d_rgb = torch.randn(B, 3, H, W, generator=g)
+    if rgb_only:
+        d_pos = torch.zeros(B, n, 2)
+        d_dep = torch.zeros(B, n)
+        d_cov = torch.zeros(B, n, 2, 2)
+    else:
+        d_pos = torch.randn(B, n, 2, generator=g)
+        d_dep = torch.randn(B, n, generator=g)
+        d_cov = torch.randn(B, n, 2, 2, generator=g)
+    L = (out["rendered_images"] * d_rgb).sum() + (out["positions"] * d_pos).sum() \
+        + (out["depths"] * d_dep).sum() + (out["scales"] * d_cov).sum()
+    L.backward()
+    order = torch.argsort(out["depths"], dim=1, descending=True)[0]
+    ys = torch.linspace(-1, 1, H)
+    xs = torch.linspace(-1, 1, W)
+    img = out["rendered_images"].detach().numpy()
+    fx = dict(
+        torch_version=np.array(torch.__version__),
+        H=np.int32(H), W=np.int32(W),
+        poses=poses.numpy().astype(np.float32),
+        positions=model.positions.detach().numpy(), scales=model.scales.detach().numpy(),
+        rotations=model.rotations.detach().numpy(), opacity=model.opacity.detach().numpy(),
+        features=model.features.detach().numpy(),
+        out_pos2d=out["positions"].detach().numpy(), out_depths=out["depths"].detach().numpy(),
+        out_cov2d=out["scales"].detach().numpy(),
+        order=order.numpy().astype(np.int64), n_composited=np.int64(calls["n"]),
+        grid_x=xs.numpy(), grid_y=ys.numpy(),
+        d_pos2d=d_pos.numpy(), d_depths=d_dep.numpy(), d_cov2d=d_cov.numpy(),
+        g_positions=model.positions.grad.numpy(), g_scales=model.scales.grad.numpy(),
+        g_rotations=model.rotations.grad.numpy(), g_opacity=model.opacity.grad.numpy(),
+        g_features=model.features.grad.numpy(),
+        analytic_upstream=np.int32(1 if analytic else 0),
+    )
+    if subsample:
+        fx["out_rgb_sub"] = img[:, :, ::subsample, ::subsample].copy()
+        fx["subsample"] = np.int32(subsample)
+        fx["out_rgb_sum"] = img.astype(np.float64).sum(axis=(2, 3))
+    else:
+        fx["out_rgb"] = img
+    if not analytic:
+        fx["d_rgb"] = d_rgb.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: N={n} B={B} {W}x{H} composited={calls['n']} "
+          f"max|rgb|={np.abs(img).max():.4f} -> {os.path.getsize(path)/1024:.0f} KiB", flush=True)
+
+
+def main():
+    big = "--big" in sys.argv
+    I3 = pose_tz(3.0)[None]
+    run_case("n1_8x8", scene_default(1, 11), I3, 8, 8, 101)
+    run_case("n2_16x12", scene_default(2, 12), I3, 12, 16, 102)
+    run_case("n64_32x24", scene_default(64, 13), I3, 24, 32, 103)
+    run_case("n300_32x24", scene_default(300, 0), I3, 24, 32, 104)            # early exit fires
+    run_case("n300_rgbonly", scene_default(300, 0), I3, 24, 32, 105, rgb_only=True)
+    run_case("c2like_2000_64x48", scene_synth(2000, 2, 0.002, 0.01), pose_tz(2.0)[None], 48, 64, 106)
+    run_case("c3like_1500_48x48_orbit", scene_synth(1500, 5, 0.001, 0.005), orbit_pose(15)[None], 48, 48, 107)
+    run_case("c5like_800_64x36", scene_synth(800, 8, 0.01, 0.1, zq=64.0), pose_tz(2.0)[None], 36, 64, 108)
+    # NOTE: no B>1 fixture exists because the reference cannot run B>1: `diff @ cov_inv.unsqueeze(1)`
+    # (gaussian_splatting.py:132) broadcasts (B,P,2)@(B,1,2,2) to (B,B,P,2) and the following
+    # .view(B,H,W) raises RuntimeError for every B>1 (observed here with B=2).
+    run_case("opac_out_of_range_64", scene_synth(64, 22, 0.01, 0.05, o_lo=-0.3, o_hi=1.4), pose_tz(2.0)[None], 24, 32, 110)
+    run_case("h1_w5_n8", scene_synth(8, 23, 0.05, 0.2), pose_tz(2.0)[None], 1, 5, 111)
+    run_case("odd_33x17_n120", scene_synth(120, 24, 0.01, 0.08), pose_tz(1.5)[None], 17, 33, 112)
+    if big:
+        # BASELINE config 1: 5000 default-init Gaussians, 400x300 (README.md:85-94); ~16 GB RSS, ~10 s
+        run_case("config1_5000_400x300", scene_default(5000, 0), I3, 300, 400, 0,
+                 rgb_only=True, subsample=4, analytic=True)
+
+
+if __name__ == "__main__":
+    main()

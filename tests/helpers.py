@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests (fixtures, error metrics, synthetic scenes)."""
+import glob
+import os
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PARAMS = ["positions", "scales", "rotations", "opacity", "features"]
+
+# tolerances stated by BASELINE.json north_star
+RGB_TOL = 1e-4          # max-abs on rendered RGB / depth
+GRAD_RTOL = 1e-3        # parameter gradients, relative to the tensor's max magnitude
+
+
+def golden_names(include_big=True):
+    names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    if not include_big:
+        names = [n for n in names if not n.startswith("config1")]
+    return names
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fx = {k: z[k] for k in z.files}
+    H, W = int(fx["H"]), int(fx["W"])
+    if int(fx["analytic_upstream"]):
+        c, y, x = np.meshgrid(np.arange(3), np.arange(H), np.arange(W), indexing="ij")
+        fx["d_rgb"] = np.sin(0.37 * c + 0.11 * y + 0.07 * x).astype(np.float32)[None]
+    fx["H"], fx["W"] = H, W
+    fx["params"] = {k: fx[k] for k in PARAMS}
+    # the reference's argsort is unstable: where depths tie its order is arbitrary, so those
+    # fixtures are replayed in the reference's own order
+    d = fx["out_depths"][0]
+    fx["has_ties"] = bool(np.unique(d).size != d.size)
+    return fx
+
+
+def rel_err(a, b):
+    """max |a-b| relative to max |b| (tensor-level relative error)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rgb_err(rgb, fx):
+    if "out_rgb" in fx:
+        return float(np.abs(rgb - fx["out_rgb"][0]).max())
+    s = int(fx["subsample"])
+    return float(np.abs(rgb[:, ::s, ::s] - fx["out_rgb_sub"][0]).max())
+
+
+def synth_scene(n, seed, s_lo, s_hi, zq=None, o_lo=0.0, o_hi=1.0):
+    """SURVEY 8d synthetic distribution with numpy's PCG64 (same on every machine)."""
+    g = np.random.default_rng(seed)
+    p = np.empty((n, 3), np.float32)
+    p[:, :2] = g.random((n, 2), np.float32) * 2 - 1
+    p[:, 2] = g.random(n, np.float32) + 0.5
+    if zq:
+        p[:, 2] = np.round(p[:, 2] * zq) / zq
+    s = np.exp(g.random((n, 3), np.float32) * (np.log(s_hi) - np.log(s_lo)) + np.log(s_lo)).astype(np.float32)
+    q = g.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    o = (g.random((n, 1), np.float32) * (o_hi - o_lo) + o_lo).astype(np.float32)
+    c = g.random((n, 3), np.float32)
+    return dict(positions=p, scales=s, rotations=q.astype(np.float32), opacity=o, features=c)
+
+
+def default_scene(n, seed):
+    """The reference's default init distributions (gaussian_splatting.py:46-63), numpy RNG."""
+    g = np.random.default_rng(seed)
+    p = (g.random((n, 3), np.float32) * 2 - 1).astype(np.float32)
+    s = (g.random((n, 3), np.float32) * 0.099 + 0.001).astype(np.float32)
+    q = np.concatenate([np.ones((n, 1), np.float32), 0.01 * g.standard_normal((n, 3)).astype(np.float32)], 1)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    o = g.random((n, 1), np.float32); c = g.random((n, 3), np.float32)
+    return dict(positions=p, scales=s, rotations=q.astype(np.float32), opacity=o, features=c)
+
+
+def pose_tz(tz):
+    p = np.eye(4, dtype=np.float32); p[2, 3] = tz
+    return p
+
+
+def orbit_pose(i, n_views=60, radius=4.0, elevation=45.0):
+    """utils/visualization.py:156-178 arithmetic in numpy (fp32 vectors like the reference)."""
+    ang = 2 * np.pi * i / n_views
+    x = radius * np.cos(ang) * np.cos(np.radians(elevation))
+    y = radius * np.sin(ang) * np.cos(np.radians(elevation))
+    z = radius * np.sin(np.radians(elevation))
+    pos = np.array([x, y, z], np.float32)
+    nrm = lambda v: (v / max(np.linalg.norm(v), 1e-12)).astype(np.float32)
+    fwd = nrm(-pos); up = np.array([0, 0, 1], np.float32)
+    right = nrm(np.cross(fwd, up)); up = nrm(np.cross(right, fwd))
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, 0] = right; pose[:3, 1] = up; pose[:3, 2] = -fwd; pose[:3, 3] = pos
+    return pose
