@@ -1,0 +1,71 @@
+"""ctypes binding of csrc/libgsplat_gfx950.so (C ABI declared in include/gsx.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgsplat_gfx950.so")
+
+# every symbol include/gsx.h declares
+SYMBOLS = [
+    "gsx_strerror", "gsx_last_hip_error", "gsx_abi_version",
+    "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32",
+    "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
+    "gsx_bin_workspace_bytes", "gsx_bin_instances",
+    "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
+]
+
+GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
+RANK_NONE = 0xFFFFFFFF
+REC_FLOATS = 12
+TILE = 16
+
+
+class GsxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.gsx_strerror(status).decode() if _lib is not None else str(status)
+        extra = f" (hipError {_lib.gsx_last_hip_error()})" if (_lib is not None and status == GSX_E_HIP) else ""
+        super().__init__(f"{where}: {msg}{extra}")
+
+
+_lib = None
+_p, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {os.path.dirname(LIB_PATH)}`; there is no CPU/torch fallback for the render path")
+    L = C.CDLL(LIB_PATH)
+    L.gsx_strerror.restype = C.c_char_p; L.gsx_strerror.argtypes = [C.c_int]
+    L.gsx_last_hip_error.restype = C.c_int
+    L.gsx_abi_version.restype = C.c_int
+    L.gsx_project_fwd.argtypes = [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]
+    L.gsx_sort_workspace_bytes.restype = _sz; L.gsx_sort_workspace_bytes.argtypes = [_i64]
+    L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _sz, _p]
+    L.gsx_scan_workspace_bytes.restype = _sz; L.gsx_scan_workspace_bytes.argtypes = [_i64]
+    L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
+    L.gsx_build_records.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    L.gsx_bin_workspace_bytes.restype = _sz; L.gsx_bin_workspace_bytes.argtypes = [_i32, _i64]
+    L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
+    L.gsx_composite_fwd.argtypes = [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]
+    L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p]
+    L.gsx_preprocess_bwd.argtypes = [_p] * 15 + [_i32, _i32] + [_p] * 6
+    for name in SYMBOLS:
+        getattr(L, name)
+        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status, where):
+    if status != GSX_OK:
+        raise GsxError(status, where)

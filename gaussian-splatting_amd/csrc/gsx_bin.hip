@@ -1,0 +1,96 @@
+// gsx_bin.hip -- tile binning: scan tiles_touched, emit (tile, rank) instances in rank order,
+// stable radix sort by tile id, cut per-tile ranges.  No counterpart in the reference, which
+// evaluates every Gaussian at every pixel (/root/reference/model/gaussian_splatting.py:118-144);
+// the integer products are bit-exact against oracle/gsx_oracle.c (gsxo_scan/emit/sort_ranges).
+#include "gsx_common.h"
+
+namespace gsx {
+
+int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, int, int,
+                        void*, size_t, hipStream_t);
+int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t);
+size_t sort_ws_bytes_internal(int64_t n);
+
+// one thread per rank: write its tiles row-major at offsets[r]..
+__global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ offsets, int N, int tw,
+                                                      uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
+{
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= N) return;
+    const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
+    const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
+    const int xlo = bx & 0xffff, xhi = bx >> 16, ylo = by & 0xffff, yhi = by >> 16;
+    if (xlo > xhi) return;
+    const int x0 = xlo >> GSX_TILE_SHIFT, x1 = (xhi >> GSX_TILE_SHIFT) + 1;
+    const int y0 = ylo >> GSX_TILE_SHIFT, y1 = (yhi >> GSX_TILE_SHIFT) + 1;
+    uint32_t o = offsets[r];
+    for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) { tiles[o] = (uint32_t)(ty * tw + tx); ranks[o] = (uint32_t)r; o++; }
+}
+
+// ranges[t] = [lower_bound(tiles, t), lower_bound(tiles, t+1))
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, uint32_t D, int n_tiles, uint32_t* __restrict__ ranges)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint32_t lb = lower_bound_u32(tiles_sorted, D, (uint32_t)t);
+    if (t < n_tiles) ranges[2*t] = lb;
+    if (t > 0) ranges[2*(t-1)+1] = lb;
+}
+
+static int tile_bits(int n_tiles) { int b = 1; while ((1 << b) < n_tiles) b++; return b; }
+
+}  // namespace gsx
+
+using namespace gsx;
+
+GSX_API size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity)
+{
+    size_t a = gsx_scan_workspace_bytes(N > 0 ? N : 1);
+    size_t b = sort_ws_bytes_internal(capacity > 0 ? capacity : 1);
+    return 256 + (a > b ? a : b);
+}
+
+GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
+                              int64_t capacity, uint32_t* offsets,
+                              uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                              uint32_t* ranges, int64_t* D_host, void* ws, size_t ws_bytes, void* stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity < 0) return GSX_E_INVALID;
+    if (!ranges || !D_host || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
+    *D_host = 0;
+    if (N == 0) { GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st)); return GSX_OK; }
+    if (!rec || !tiles_touched || !offsets) return GSX_E_INVALID;
+    uint64_t* total_dev = (uint64_t*)ws;
+    void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
+    int s = scan_internal(tiles_touched, offsets, total_dev, N, sub_ws, sub_bytes, st);
+    if (s != GSX_OK) return s;
+    uint64_t D = 0;
+    GSX_HIP(hipMemcpyAsync(&D, total_dev, 8, hipMemcpyDeviceToHost, st));
+    GSX_HIP(hipStreamSynchronize(st));
+    *D_host = (int64_t)D;
+    if (D >= 0xFFFFFFFFull) return GSX_E_RANGE;
+    if ((int64_t)D > capacity) return GSX_E_CAPACITY;
+    if (D == 0) { GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st)); return GSX_OK; }
+    if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
+    const int bits = tile_bits(n_tiles);
+    const int passes = (bits + 7) / 8;
+    // emit into the buffer the sort does NOT write first, so that the last pass lands in *_sorted
+    uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;
+    uint32_t* e_r = (passes & 1) ? ranks_tmp : ranks_sorted;
+    emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, e_t, e_r);
+    GSX_LAUNCH_CHECK();
+    s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, (int64_t)D, 0, bits, sub_ws, sub_bytes, st);
+    if (s != GSX_OK) return s;
+    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, (uint32_t)D, n_tiles, ranges);
+    GSX_LAUNCH_CHECK();
+    return GSX_OK;
+}

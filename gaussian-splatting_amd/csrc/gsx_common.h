@@ -1,0 +1,48 @@
+// gsx_common.h -- shared host/device helpers of libgsplat_gfx950.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gsx.h"
+
+#define GSX_API extern "C" __attribute__((visibility("default")))
+
+namespace gsx {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_check(hipError_t e)
+{
+    if (e == hipSuccess) return GSX_OK;
+    g_last_hip_error = (int)e;
+    return GSX_E_HIP;
+}
+#define GSX_HIP(expr) do { int _s = gsx::hip_check(expr); if (_s != GSX_OK) return _s; } while (0)
+#define GSX_LAUNCH_CHECK() GSX_HIP(hipGetLastError())
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+constexpr int kBlock = 256;        // 4 wave64
+constexpr int kWave = 64;
+
+// -0.5 * log2(e): conic pre-multiplier so that alpha = o * exp2(q')
+#define GSX_NEG_HALF_LOG2E (-0.72134752f)
+#define GSX_LN2 0.69314718f
+
+// ---- wave64 DPP reductions (row = 16 lanes) -------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row_sum16(float v)
+{
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+
+}  // namespace gsx

@@ -1,0 +1,278 @@
+// gsx_sort.hip -- device exclusive scan and stable LSD radix sort of (u32 key, u32 value) pairs
+// for gfx950 (wave64).  Used twice on the render path:
+//   * depth order: keys = order-preserving depth bits (32 bits, 4 passes), values = Gaussian index
+//     (replaces torch.argsort, /root/reference/model/gaussian_splatting.py:198)
+//   * binning: keys = tile id (ceil(log2(tiles)) bits, usually 2 passes), values = depth rank;
+//     instances are emitted in rank order, so a STABLE sort on the tile id alone yields the
+//     (tile << 32 | rank) key order with 4-byte keys and 2 passes instead of 64-bit keys and 5.
+// HBM-bound integer work: coalesced 4-byte streams, digit ranking with wave64 ballots, no MFMA.
+#include "gsx_common.h"
+
+namespace gsx {
+
+thread_local int g_last_hip_error = 0;
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan (u32 values, u64 block sums / total)
+// ------------------------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;   // 2048
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ block_sums)
+{
+    __shared__ uint64_t s_w[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        int64_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// single workgroup: exclusive scan of nb u64 block sums in place; total -> *total
+__global__ __launch_bounds__(kBlock) void scan_top_kernel(uint64_t* __restrict__ block_sums, int64_t nb, uint64_t* __restrict__ total)
+{
+    __shared__ uint64_t s_w[4];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t start = 0; start < nb; start += kBlock) {
+        int64_t i = start + threadIdx.x;
+        uint64_t v = (i < nb) ? block_sums[i] : 0, incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint64_t base = s_carry;
+        for (int w = 0; w < wave; w++) base += s_w[w];
+        if (i < nb) block_sums[i] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_carry = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
+                                                            const uint64_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;   // blocked layout
+    uint32_t v[kScanItems]; uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; v[k] = (i < n) ? in[i] : 0u; s += v[k]; }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_u32(s, s_wave, &tot) + (uint32_t)block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+}
+
+static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    int64_t nb = ceil_div(n, kScanTile);
+    if (ws_bytes < (size_t)nb * 8) return GSX_E_CAPACITY;
+    uint64_t* sums = (uint64_t*)ws;
+    scan_reduce_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, n, sums);
+    scan_top_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(sums, nb, total_dev);
+    scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, sums);
+    GSX_LAUNCH_CHECK();
+    return GSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// radix sort, 8-bit digits
+// ------------------------------------------------------------------------------------------
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kSortItems = 16;                      // keys per thread
+constexpr int kSortTile = kBlock * kSortItems;      // 4096 keys per workgroup
+
+// hist[d * nb + b] = number of keys of workgroup b with digit d
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t mask,
+                                                            uint32_t* __restrict__ hist, uint32_t nb)
+{
+    __shared__ uint32_t s_hist[kRadix];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        int64_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nb + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               int64_t n, int shift, uint32_t mask,
+                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nb)
+{
+    __shared__ uint32_t s_run[kRadix];        // next free global slot per digit for this workgroup
+    __shared__ uint32_t s_cnt[4][kRadix];     // per-wave counts of the round -> per-wave base slots
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    s_run[tid] = hist_scanned[(size_t)tid * nb + blockIdx.x];
+
+    uint32_t key[kSortItems], val[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        int64_t i = base + k * kBlock + tid;
+        key[k] = (i < n) ? keys_in[i] : 0xFFFFFFFFu;
+        val[k] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const int64_t i = base + k * kBlock + tid;
+        const bool valid = i < n;
+        const uint32_t d = (key[k] >> shift) & mask;
+        s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
+        // lanes of this wave holding the same digit (stable: lane order == key order)
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(peers & lt_mask);
+        __syncthreads();
+        if (valid && rank == 0) s_cnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        {
+            const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+            const uint32_t r0 = s_run[tid];
+            s_cnt[0][tid] = r0; s_cnt[1][tid] = r0 + c0; s_cnt[2][tid] = r0 + c0 + c1; s_cnt[3][tid] = r0 + c0 + c1 + c2;
+            s_run[tid] = r0 + c0 + c1 + c2 + c3;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t dst = s_cnt[wave][d] + rank;
+            keys_out[dst] = key[k];
+            vals_out[dst] = val[k];
+        }
+        __syncthreads();
+    }
+}
+
+static size_t sort_ws_bytes(int64_t n)
+{
+    int64_t nb = ceil_div(n > 0 ? n : 1, kSortTile);
+    int64_t hist_n = nb * kRadix;
+    return align_up((size_t)hist_n * 4) + align_up((size_t)ceil_div(hist_n, kScanTile) * 8);
+}
+
+// Sorts n pairs on key bits [begin_bit, end_bit).  Pass 0 reads (k_in, v_in); passes alternate
+// between (k_a, v_a) and (k_b, v_b) such that the LAST pass writes (k_a, v_a).  No pass reads and
+// writes the same buffer provided k_in differs from the first destination:
+//   odd pass count  -> first destination is a;  even -> first destination is b.
+int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_a, uint32_t* v_a,
+                        uint32_t* k_b, uint32_t* v_b, int64_t n, int begin_bit, int end_bit,
+                        void* ws, size_t ws_bytes, hipStream_t st)
+{
+    if (n <= 0) return GSX_OK;
+    if (n >= (int64_t)0xFFFFFFFFll) return GSX_E_RANGE;
+    if (ws_bytes < sort_ws_bytes(n)) return GSX_E_CAPACITY;
+    const int passes = (end_bit - begin_bit + kRadixBits - 1) / kRadixBits;
+    const uint32_t nb = (uint32_t)ceil_div(n, kSortTile);
+    const int64_t hist_n = (int64_t)nb * kRadix;
+    uint32_t* hist = (uint32_t*)ws;
+    void* scan_ws = (char*)ws + align_up((size_t)hist_n * 4);
+    size_t scan_ws_bytes = ws_bytes - align_up((size_t)hist_n * 4);
+    if (passes == 0) {   // nothing to sort on: copy through
+        GSX_HIP(hipMemcpyAsync(k_a, k_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        if (v_in) GSX_HIP(hipMemcpyAsync(v_a, v_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        return GSX_OK;
+    }
+    const uint32_t* ks = k_in; const uint32_t* vs = v_in;
+    for (int p = 0; p < passes; p++) {
+        const bool to_a = ((passes - 1 - p) % 2) == 0;
+        uint32_t* kd = to_a ? k_a : k_b; uint32_t* vd = to_a ? v_a : v_b;
+        const int shift = begin_bit + p * kRadixBits;
+        const int bits = (end_bit - shift) < kRadixBits ? (end_bit - shift) : kRadixBits;
+        const uint32_t mask = (1u << bits) - 1u;
+        radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, shift, mask, hist, nb);
+        int s = scan_launch(hist, hist, nullptr, hist_n, scan_ws, scan_ws_bytes, st);
+        if (s != GSX_OK) return s;
+        radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, shift, mask, hist, nb);
+        GSX_LAUNCH_CHECK();
+        ks = kd; vs = vd;
+    }
+    return GSX_OK;
+}
+
+int scan_internal(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    if (n <= 0) {
+        if (total_dev) GSX_HIP(hipMemsetAsync(total_dev, 0, 8, st));
+        return GSX_OK;
+    }
+    return scan_launch(in, out, total_dev, n, ws, ws_bytes, st);
+}
+
+size_t sort_ws_bytes_internal(int64_t n) { return sort_ws_bytes(n); }
+
+}  // namespace gsx
+
+using namespace gsx;
+
+GSX_API size_t gsx_sort_workspace_bytes(int64_t n) { return sort_ws_bytes(n); }
+
+GSX_API int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
+                               uint32_t* keys_tmp, uint32_t* values_tmp, int64_t n, int begin_bit, int end_bit,
+                               void* ws, size_t ws_bytes, void* stream)
+{
+    if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSX_E_INVALID;
+    if (n == 0) return GSX_OK;
+    if (!keys_in || !keys_out || !values_out || !keys_tmp || !values_tmp || !ws) return GSX_E_INVALID;
+    if (keys_in == keys_out || keys_in == keys_tmp || keys_out == keys_tmp) return GSX_E_INVALID;
+    return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, begin_bit, end_bit,
+                               ws, ws_bytes, (hipStream_t)stream);
+}
+
+GSX_API size_t gsx_scan_workspace_bytes(int64_t n) { return align_up((size_t)ceil_div(n > 0 ? n : 1, kScanTile) * 8); }
+
+GSX_API int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* total_dev, int64_t n,
+                         void* ws, size_t ws_bytes, void* stream)
+{
+    if (n < 0) return GSX_E_INVALID;
+    if (n > 0 && (!in || !out_exclusive || !ws)) return GSX_E_INVALID;
+    return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,207 @@
+"""Host side of the gfx950 render path: orchestrates the C-ABI kernels for one view and wraps
+them in a torch.autograd.Function.  torch is used for device memory, streams and autograd
+plumbing only; all arithmetic of the path runs in csrc/libgsplat_gfx950.so.
+
+Replaces GaussianSplat._forward_impl / _render_chunk and the autograd graph recorded over them
+(/root/reference/model/gaussian_splatting.py:70-154, 188-344).
+"""
+import ctypes as C
+import torch
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Scratch:
+    """Per-device grow-only scratch for binning (instance buffers are sized by the data)."""
+    def __init__(self):
+        self.capacity = {}
+
+    def cap(self, dev, n):
+        return self.capacity.get(dev, max(4 * n, 1 << 16))
+
+    def grow(self, dev, d):
+        self.capacity[dev] = int(d * 1.25) + 4096
+
+
+_scratch = _Scratch()
+
+
+def depth_order(depth_keys):
+    """order[r] = index of the Gaussian composited r-th (descending depth, ties by index)."""
+    lib = L.lib()
+    n = depth_keys.numel()
+    dev = depth_keys.device
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    k_out = torch.empty(n, dtype=torch.int32, device=dev)
+    k_tmp = torch.empty(n, dtype=torch.int32, device=dev)
+    v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
+    wsb = lib.gsx_sort_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    L.check(lib.gsx_sort_pairs_u32(_ptr(depth_keys), None, _ptr(k_out), _ptr(order), _ptr(k_tmp), _ptr(v_tmp),
+                                   n, 0, 32, _ptr(ws), wsb, _stream()), "gsx_sort_pairs_u32")
+    return order
+
+
+def project(positions, scales, rotations, pose):
+    lib = L.lib()
+    n = positions.shape[0]; dev = positions.device
+    mean2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    depth = torch.empty(n, dtype=torch.float32, device=dev)
+    cov2d = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
+    keys = torch.empty(n, dtype=torch.int32, device=dev)
+    L.check(lib.gsx_project_fwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(pose), n,
+                                _ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(keys), _stream()), "gsx_project_fwd")
+    return mean2d, depth, cov2d, keys
+
+
+def build_records(mean2d, depth, cov2d, opacity, features, order, H, W):
+    lib = L.lib()
+    n = order.numel(); dev = order.device
+    rec = torch.empty(n, L.REC_FLOATS, dtype=torch.float32, device=dev)
+    tt = torch.empty(n, dtype=torch.int32, device=dev)
+    L.check(lib.gsx_build_records(_ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(opacity), _ptr(features), _ptr(order),
+                                  n, H, W, _ptr(rec), _ptr(tt), _stream()), "gsx_build_records")
+    return rec, tt
+
+
+def bin_instances(rec, tt, H, W):
+    """-> offsets, tiles_sorted[:D], ranks_sorted[:D], ranges (n_tiles,2), D"""
+    lib = L.lib()
+    n = tt.numel(); dev = tt.device
+    tw, th = (W + L.TILE - 1) // L.TILE, (H + L.TILE - 1) // L.TILE
+    offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ranges = torch.empty(tw * th, 2, dtype=torch.int32, device=dev)
+    D = C.c_int64(0)
+    for _attempt in range(2):
+        cap = _scratch.cap(dev, n)
+        bufs = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
+        wsb = lib.gsx_bin_workspace_bytes(n, cap)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        st = lib.gsx_bin_instances(_ptr(rec), _ptr(tt), n, H, W, cap, _ptr(offsets), _ptr(bufs[0]), _ptr(bufs[1]),
+                                   _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), C.byref(D), _ptr(ws), wsb, _stream())
+        if st == L.GSX_E_CAPACITY:
+            _scratch.grow(dev, D.value)
+            continue
+        L.check(st, "gsx_bin_instances")
+        break
+    else:
+        raise L.GsxError(L.GSX_E_CAPACITY, "gsx_bin_instances")
+    return offsets, bufs[0], bufs[1], ranges, int(D.value)
+
+
+def composite_forward(rec, ranks_sorted, ranges, n, H, W, want_depth=True):
+    lib = L.lib()
+    dev = rec.device
+    rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
+    state = torch.empty(1, dtype=torch.int32, device=dev)
+    for p in (0, 1):
+        L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), n, H, W, p, _ptr(state),
+                                      _ptr(rgb), _ptr(alpha), _ptr(dmap), _stream()), "gsx_composite_fwd")
+    return rgb, alpha, dmap, state
+
+
+class ViewState:
+    """Everything one view's backward needs (kept alive by the autograd node)."""
+    __slots__ = ("pose", "order", "rec", "tt", "offsets", "ranks", "ranges", "state", "rgb", "D", "H", "W")
+
+
+def forward_view(params, pose, H, W, order=None, want_depth=True):
+    """One view. params = (positions, scales, rotations, opacity, features), fp32 contiguous CUDA."""
+    positions, scales, rotations, opacity, features = params
+    n = positions.shape[0]
+    mean2d, depth, cov2d, keys = project(positions, scales, rotations, pose)
+    if order is None:
+        order = depth_order(keys)
+    rec, tt = build_records(mean2d, depth, cov2d, opacity, features, order, H, W)
+    offsets, tiles, ranks, ranges, D = bin_instances(rec, tt, H, W)
+    rgb, alpha, dmap, state = composite_forward(rec, ranks, ranges, n, H, W, want_depth)
+    vs = ViewState()
+    vs.pose, vs.order, vs.rec, vs.tt, vs.offsets = pose, order, rec, tt, offsets
+    vs.ranks, vs.ranges, vs.state, vs.rgb, vs.D, vs.H, vs.W = ranks, ranges, state, rgb, D, H, W
+    vs_extra = dict(tiles=tiles)
+    return (rgb, alpha, dmap, mean2d, depth, cov2d), vs, vs_extra
+
+
+def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumulate):
+    """Adds (or writes) this view's parameter gradients into `grads` (5 tensors)."""
+    lib = L.lib()
+    positions, scales, rotations, opacity, features = params
+    n = positions.shape[0]; dev = positions.device
+    partials = None
+    if d_rgb is not None and vs.D > 0:
+        partials = torch.empty(vs.D, 9, dtype=torch.float32, device=dev)
+        L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.offsets), n, vs.H, vs.W,
+                                      _ptr(vs.state), _ptr(vs.rgb), _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
+    L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features),
+                                   _ptr(vs.pose), _ptr(vs.order), _ptr(vs.rec), _ptr(vs.offsets), _ptr(vs.tt),
+                                   _ptr(partials), _ptr(vs.state), _ptr(d_mean2d), _ptr(d_depth), _ptr(d_cov2d),
+                                   n, 1 if accumulate else 0, *[_ptr(g) for g in grads], _stream()), "gsx_preprocess_bwd")
+
+
+class RenderFunction(torch.autograd.Function):
+    """(positions, scales, rotations, opacity, features, poses (B,4,4)) ->
+       rendered_images (B,3,H,W), positions2d (B,N,2), depths (B,N), cov2d (B,N,2,2),
+       alpha (B,1,H,W), depth_map (B,1,H,W), n_composited-state (B,) [last three non-differentiable]"""
+
+    @staticmethod
+    def forward(ctx, positions, scales, rotations, opacity, features, poses, H, W):
+        if not positions.is_cuda:
+            raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
+                               "there is no CPU fallback")
+        ctx.set_materialize_grads(False)
+        params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
+        poses = _f32c(poses.detach())
+        B = poses.shape[0]
+        outs, views = [], []
+        order = None
+        for b in range(B):
+            o, vs, _ = forward_view(params, poses[b], H, W, order=order)
+            if order is None:
+                order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
+            outs.append(o); views.append(vs)
+        ctx.params, ctx.views, ctx.hw = params, views, (H, W)
+        rgb = torch.stack([o[0] for o in outs]); alpha = torch.stack([o[1] for o in outs])
+        dmap = torch.stack([o[2] for o in outs]); mean2d = torch.stack([o[3] for o in outs])
+        depth = torch.stack([o[4] for o in outs]); cov2d = torch.stack([o[5] for o in outs])
+        state = torch.cat([vs.state for vs in views])
+        ctx.mark_non_differentiable(alpha, dmap, state)
+        return rgb, mean2d, depth, cov2d, alpha, dmap, state
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_mean2d, d_depth, d_cov2d, _a, _d, _s):
+        params = ctx.params
+        n = params[0].shape[0]
+        # one flat 14*N gradient buffer (rotations first: its float4 stores need 16-byte alignment);
+        # the data-parallel path all-reduces this buffer in ONE collective (distributed.py)
+        flat = torch.empty(14 * n, dtype=torch.float32, device=params[0].device)
+        g_rot = flat[0:4 * n].view(n, 4); g_pos = flat[4 * n:7 * n].view(n, 3); g_scl = flat[7 * n:10 * n].view(n, 3)
+        g_opa = flat[10 * n:11 * n].view(n, 1); g_fea = flat[11 * n:14 * n].view(n, 3)
+        grads = [g_pos, g_scl, g_rot, g_opa, g_fea]
+        for b, vs in enumerate(ctx.views):
+            backward_view(params, vs,
+                          None if d_rgb is None else _f32c(d_rgb[b]),
+                          None if d_mean2d is None else _f32c(d_mean2d[b]),
+                          None if d_depth is None else _f32c(d_depth[b]),
+                          None if d_cov2d is None else _f32c(d_cov2d[b]),
+                          grads, accumulate=(b > 0))
+        return grads[0], grads[1], grads[2], grads[3], grads[4], None, None, None
+
+
+def render_views(positions, scales, rotations, opacity, features, poses, image_size):
+    H, W = int(image_size[0]), int(image_size[1])
+    return RenderFunction.apply(positions, scales, rotations, opacity, features, poses, H, W)

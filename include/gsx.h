@@ -1,0 +1,130 @@
+/* gsx.h -- C ABI of libgsplat_gfx950.so: the MI355X (gfx950) Gaussian-splat render path.
+ *
+ * Drop-in boundary for ONE hot path of ChristianLin0420/gaussian-splatting:
+ * GaussianSplat.forward and its (implicit, autograd) backward.  The reference has no FFI for
+ * this path -- it is ~25 ATen calls per Gaussian issued from Python
+ * (/root/reference/model/gaussian_splatting.py:70-344) -- so each entry point below cites the
+ * reference lines whose work it replaces.  The Python side that binds these with ctypes is
+ * gaussian-splatting_amd/_lib.py; INTEGRATION.md shows the stub a maintainer of the reference adds.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types; return 0 (GSX_OK) or a negative GSX_E_*.
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in _host;
+ *     nothing here allocates or frees device memory.
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous; only
+ *     gsx_bin_instances synchronises the stream once (8-byte read-back of the instance count).
+ *   - fp32 arithmetic; integer products (sort keys, tile rectangles, tile ranges) are bit-exact
+ *     against oracle/gsx_oracle.c.
+ *   - re-entrant; no global state.  One host thread per stream.
+ */
+#ifndef GSX_H
+#define GSX_H
+#include <stddef.h>
+#include <stdint.h>
+#include "gsx_constants.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_OK 0
+#define GSX_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, misaligned) */
+#define GSX_E_CAPACITY (-2)    /* caller's instance buffers / workspace too small; see out parameter */
+#define GSX_E_HIP (-3)         /* a HIP runtime call failed; gsx_last_hip_error() has the code */
+#define GSX_E_RANGE (-4)       /* problem exceeds 32-bit instance indexing */
+
+const char* gsx_strerror(int status);
+int gsx_last_hip_error(void);
+/* ABI version; bumped on any signature change */
+int gsx_abi_version(void);
+
+/* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
+ * _quaternion_to_rotation_matrix, _compute_jacobian (gaussian_splatting.py:221-344).
+ * One thread per Gaussian.  Outputs are the reference's returned tensors for ONE view:
+ *   mean2d (N,2) = 'positions', depth (N) = 'depths', cov2d (N,2,2) = 'scales',
+ * plus depth_key (N) u32: ascending-unsigned order == descending depth (the order
+ * torch.argsort(depths, descending=True) produces, :198), -0 folded onto +0. */
+int gsx_project_fwd(const float* positions, const float* scales, const float* rotations,
+                    const float* pose /* 16 floats, row-major 4x4 */, int32_t N,
+                    float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, void* stream);
+
+/* ---- device LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit),
+ * stable.  values_in == NULL means values are 0..n-1.  Result lands in keys_out/values_out;
+ * keys_tmp/values_tmp are ping-pong buffers of n elements.  ws: gsx_sort_workspace_bytes(n).
+ * Replaces torch.argsort (:198) [keys = depth_key, 32 bits] and is reused to order the
+ * (tile, rank) instances by tile [keys = tile id]. */
+size_t gsx_sort_workspace_bytes(int64_t n);
+int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_in,
+                       uint32_t* keys_out, uint32_t* values_out,
+                       uint32_t* keys_tmp, uint32_t* values_tmp,
+                       int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- exclusive prefix sum of n u32; total (u64) written to *total_dev.  ws: gsx_scan_workspace_bytes(n). */
+size_t gsx_scan_workspace_bytes(int64_t n);
+int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* total_dev, int64_t n,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---- rank-ordered splat records: replaces the per-Gaussian gathers and torch.inverse of
+ * _render_chunk (:110-115, :128-130) and adds the footprint rectangle (no counterpart in the
+ * reference: it evaluates every Gaussian at every pixel).  order[r] = Gaussian composited r-th.
+ * rec: N x GSX_REC_FLOATS floats (layout: gsx_constants.h); tiles_touched: N. */
+int gsx_build_records(const float* mean2d, const float* depth, const float* cov2d,
+                      const float* opacity, const float* features, const uint32_t* order,
+                      int32_t N, int32_t H, int32_t W, float* rec, uint32_t* tiles_touched, void* stream);
+
+/* ---- binning: scan tiles_touched -> offsets, emit (tile, rank) instances, sort them by tile
+ * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), and cut tile
+ * ranges.  Synchronises `stream` once to read the instance count D back.
+ *   capacity     : elements available in each of the four instance buffers
+ *   offsets      : N u32 (exclusive scan of tiles_touched, rank order)
+ *   tiles_sorted / ranks_sorted : results (D valid elements)
+ *   tiles_tmp / ranks_tmp       : scratch of the same capacity
+ *   ranges       : n_tiles x 2 u32, ranges[t] = [lower_bound(t), lower_bound(t+1)) into the sorted arrays
+ *   *D_host      : instance count (also on GSX_E_CAPACITY, so the caller can grow and retry)
+ * ws: gsx_bin_workspace_bytes(N, capacity). */
+size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity);
+int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
+                      int64_t capacity, uint32_t* offsets,
+                      uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                      uint32_t* ranges, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  One 256-thread
+ * workgroup per 16x16 tile; splat records staged through LDS in batches of 256.
+ *   state[0] (u32, in/out): saturation rank.  gsx_composite_fwd with pass = 0 composites every
+ *       instance and writes max over pixels of the first rank after which accumulated alpha
+ *       > 0.99 (GSX_RANK_NONE if some pixel never saturates) -- the reference's global early
+ *       exit index (:147).  With pass = 1 it reads state[0] and re-composites, only if the exit
+ *       fired, the tiles that hold ranks beyond it, stopping at the exit rank.
+ *   rgb (3,H,W), alpha (H,W) accumulated alpha, depth_map (H,W) or NULL. */
+int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                      int32_t N, int32_t H, int32_t W, int32_t pass, uint32_t* state,
+                      float* rgb, float* alpha, float* depth_map, void* stream);
+
+/* ---- backward of compositing (the reference relies on autograd over :124-144).  Walks each
+ * tile's list front to back again, reduces the nine per-splat partial sums over the wavefront
+ * (DPP) and the workgroup (LDS) and stores ONE row per (tile, rank) instance at
+ * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
+ * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
+ *   partials: capacity >= D rows of 9 floats.  state[0]: as left by the forward. */
+int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                      const uint32_t* offsets, int32_t N, int32_t H, int32_t W, const uint32_t* state,
+                      const float* rgb, const float* d_rgb, float* partials, void* stream);
+
+/* ---- backward of records + projection: sums each splat's partial rows, then chains through
+ * the 2x2 inverse, J*Sigma3*J^T, R(q)diag(s^2)R(q)^T, quaternion normalisation and the
+ * perspective division (autograd of :221-344).  d_mean2d/d_depth/d_cov2d are upstream
+ * gradients on the returned 'positions'/'depths'/'scales' (may be NULL).  Gradients of the
+ * five parameters are written (accumulate = 0) or added (accumulate = 1) at Gaussian order. */
+int gsx_preprocess_bwd(const float* positions, const float* scales, const float* rotations,
+                       const float* opacity, const float* features, const float* pose,
+                       const uint32_t* order, const float* rec, const uint32_t* offsets,
+                       const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
+                       const float* d_mean2d, const float* d_depth, const float* d_cov2d,
+                       int32_t N, int32_t accumulate,
+                       float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
+                       float* g_features, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -25,10 +25,12 @@
 #define GSX_SAT_ALPHA 0.99f
 
 /* floats per rank-ordered splat record:
- *  0 mu_x  1 mu_y  2 k00  3 kb   | 4 k11  5 opacity  6 r  7 g | 8 b  9 depth  10 rect_lo  11 rect_hi
+ *  0 mu_x  1 mu_y  2 k00  3 kb   | 4 k11  5 opacity  6 r  7 g | 8 b  9 depth  10 box_x  11 box_y
  * k00,kb,k11 = conic (M00, M01+M10, M11) pre-multiplied by -0.5*log2(e) so that
  * alpha = opacity * exp2(k00*dx*dx + kb*dx*dy + k11*dy*dy).
- * rect_lo / rect_hi are the bit patterns of (x0 | y0<<16) and (x1 | y1<<16), tile units, x1/y1 exclusive. */
+ * box_x / box_y are the bit patterns of (xlo | xhi<<16) and (ylo | yhi<<16): the footprint's pixel
+ * bounding box, inclusive, clamped to the image; lo > hi (1,0) marks an empty footprint.  The tile
+ * rectangle is [lo >> 4, (hi >> 4) + 1).  Images are limited to 65535 pixels per side. */
 #define GSX_REC_FLOATS 12
 
 /* "no saturation" marker for the per-pixel saturation rank */

@@ -173,34 +173,38 @@ static float inv2x2(float a, float b, float c, float d, float* m)
 #define NEG_HALF_LOG2E (-0.72134752f)
 
 static void footprint(float mx, float my, float a, float d, float det, float op, int W, int H,
-                      int tw, int th, int32_t* rc)
+                      int32_t* rc /* tile rect x0,y0,x1,y1 (exclusive) */, int32_t* px /* pixel box xlo,ylo,xhi,yhi inclusive */)
 {
     uint32_t ob; memcpy(&ob, &op, 4); ob &= 0x7fffffffu;
     int e = (int)(ob >> 23) - 127;                 /* |o| < 2^(e+1) */
     int m = e + 1 + GSX_CUT_LOG2;
     rc[0] = rc[1] = rc[2] = rc[3] = 0;
+    px[0] = px[1] = 1; px[2] = px[3] = 0;          /* empty box: lo > hi */
     if (ob < 0x7f800000u && m <= 0) return;                              /* |alpha| < 2^-CUT everywhere */
     int full = !(ob < 0x7f800000u);                                      /* inf / nan opacity */
     float kap2 = GSX_TWO_LN2 * (float)m;
     float ex = sqrtf(kap2 * a), ey = sqrtf(kap2 * d);
     if (!(a > 0.0f) || !(d > 0.0f) || !(det > 0.0f)) full = 1;          /* not positive definite */
     if (!(fabsf(mx) <= 3.0e38f) || !(fabsf(my) <= 3.0e38f) || !(ex <= 3.0e38f) || !(ey <= 3.0e38f)) full = 1;
-    if (full) { rc[0] = 0; rc[1] = 0; rc[2] = tw; rc[3] = th; return; }
-    float hx = 0.5f * (float)(W - 1), hy = 0.5f * (float)(H - 1);
-    float xlo = ceilf((mx - ex + 1.0f) * hx), xhi = floorf((mx + ex + 1.0f) * hx);
-    float ylo = ceilf((my - ey + 1.0f) * hy), yhi = floorf((my + ey + 1.0f) * hy);
-    xlo = fmaxf(xlo, 0.0f); ylo = fmaxf(ylo, 0.0f);
-    xhi = fminf(xhi, (float)(W - 1)); yhi = fminf(yhi, (float)(H - 1));
-    if (!(xlo <= xhi) || !(ylo <= yhi)) return;                          /* off screen */
-    rc[0] = (int)xlo >> GSX_TILE_SHIFT; rc[1] = (int)ylo >> GSX_TILE_SHIFT;
-    rc[2] = ((int)xhi >> GSX_TILE_SHIFT) + 1; rc[3] = ((int)yhi >> GSX_TILE_SHIFT) + 1;
+    float xlo, xhi, ylo, yhi;
+    if (full) { xlo = 0.0f; ylo = 0.0f; xhi = (float)(W - 1); yhi = (float)(H - 1); }
+    else {
+        float hx = 0.5f * (float)(W - 1), hy = 0.5f * (float)(H - 1);
+        xlo = ceilf((mx - ex + 1.0f) * hx); xhi = floorf((mx + ex + 1.0f) * hx);
+        ylo = ceilf((my - ey + 1.0f) * hy); yhi = floorf((my + ey + 1.0f) * hy);
+        xlo = fmaxf(xlo, 0.0f); ylo = fmaxf(ylo, 0.0f);
+        xhi = fminf(xhi, (float)(W - 1)); yhi = fminf(yhi, (float)(H - 1));
+        if (!(xlo <= xhi) || !(ylo <= yhi)) return;                      /* off screen */
+    }
+    px[0] = (int)xlo; px[1] = (int)ylo; px[2] = (int)xhi; px[3] = (int)yhi;
+    rc[0] = px[0] >> GSX_TILE_SHIFT; rc[1] = px[1] >> GSX_TILE_SHIFT;
+    rc[2] = (px[2] >> GSX_TILE_SHIFT) + 1; rc[3] = (px[3] >> GSX_TILE_SHIFT) + 1;
 }
 
 API void gsxo_records(const float* mean2d, const float* depth, const float* cov2d,
                       const float* opacity, const float* features, const uint32_t* order,
                       int N, int H, int W, float* rec, int32_t* rect, uint32_t* tiles_touched)
 {
-    int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
     #pragma omp parallel for schedule(static)
     for (int r = 0; r < N; r++) {
         uint32_t g = order[r];
@@ -211,10 +215,10 @@ API void gsxo_records(const float* mean2d, const float* depth, const float* cov2
         R[2] = m[0] * NEG_HALF_LOG2E; R[3] = (m[1] + m[2]) * NEG_HALF_LOG2E; R[4] = m[3] * NEG_HALF_LOG2E;
         R[5] = opacity[g]; R[6] = features[3*g]; R[7] = features[3*g+1]; R[8] = features[3*g+2];
         R[9] = depth[g];
-        int32_t* rc = rect + 4*r;
-        footprint(R[0], R[1], a, d, det, R[5], W, H, tw, th, rc);
-        uint32_t lo = (uint32_t)rc[0] | ((uint32_t)rc[1] << 16), hi = (uint32_t)rc[2] | ((uint32_t)rc[3] << 16);
-        memcpy(R + 10, &lo, 4); memcpy(R + 11, &hi, 4);
+        int32_t* rc = rect + 4*r; int32_t px[4];
+        footprint(R[0], R[1], a, d, det, R[5], W, H, rc, px);
+        uint32_t bx = (uint32_t)px[0] | ((uint32_t)px[2] << 16), by = (uint32_t)px[1] | ((uint32_t)px[3] << 16);
+        memcpy(R + 10, &bx, 4); memcpy(R + 11, &by, 4);
         tiles_touched[r] = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
     }
 }
