@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd splat-render throughput of the gfx950 path on BASELINE.json's metric
+configuration: 1M Gaussians, 1024x1024, the 60-view orbit of config 3 (SURVEY 8d seed 5).
+
+    python bench.py --gpus 1 --steps 60 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one trainer step on one view per GPU (trainer.py:134-175 sequence): zero_grad ->
+render forward -> L1 loss -> render backward -> [N>1: one RCCL all-reduce of the flat 14*N
+gradient buffer] -> clip_grad_norm_(0.1) -> Adam step.  View of rank r at step s is
+(s*N + r) mod 60: views are sharded over GPUs, per-GPU work is fixed (weak scaling).
+value = N * K * H * W / max-over-ranks wall time / 1e6 (Mpix/s), inputs resident in HBM.
+
+Rank 0 also reports (same JSON line):
+  roofline      dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline  the CPU oracle (tiled restatement, "port") timed on the host for ONE view
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+
+def algorithmic_bytes(stage, n, d, p):
+    """HBM bytes one launch must move assuming perfect on-chip reuse inside the kernel."""
+    return {
+        # rank 4 + record 48 per instance; rgb 12 + alpha 4 + depth 4 per pixel; ranges 8 per tile
+        "composite_fwd": 52 * d + 20 * p,
+        # rank 4 + record 48 + offset 4 + partial row 36 per instance; rgb 12 + d_rgb 12 per pixel
+        "composite_bwd": 92 * d + 24 * p,
+        "project_fwd": (40 + 32) * n,
+        "depth_sort": 4 * (8 + 8 + 8) * n,                # 4 passes: hist read 4, scatter read 8 + write 8 (+ index)
+        "build_records": (4 + 28 + 16 + 48 + 4) * n,
+        "bin_instances": 8 * n + 8 * d + 2 * (4 + 8 + 8) * d + 8 * d,
+        "preprocess_bwd": (4 + 40 + 16 + 28 + 56) * n + 36 * d,
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", help="scene config (c2/c3/c4/c5); the metric is quoted on c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time render fwd+bwd(+all-reduce) only")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd import render as R
+    from gaussian_splatting_amd.scenes import config_scene, create_orbit_poses
+    from gaussian_splatting_amd.distributed import DataParallelSplat
+    from gaussian_splatting_amd.trainer import make_optimizer, train_step, l1_loss
+
+    params, H, W = config_scene(args.config)
+    n = params["positions"].shape[0]
+    model = GaussianSplat(n)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(dev)
+    net = DataParallelSplat(model) if world > 1 else model
+    opt = make_optimizer(net)
+    n_views = 60
+    poses = torch.from_numpy(create_orbit_poses(4.0, n_views, 45.0)).to(dev)      # README.md:129-137
+    g = torch.Generator(device="cpu").manual_seed(3)
+    target = torch.rand(1, 3, H, W, generator=g).to(dev)
+
+    def step(s):
+        v = (s * world + rank) % n_views
+        if args.no_optimizer:
+            opt.zero_grad()
+            out = net(poses[v:v + 1], (H, W))
+            l1_loss(out, target).backward()
+        else:
+            train_step(net, opt, poses[v:v + 1], target, l1_loss, max_grad_norm=0.1)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream) over one more orbit pass, rank 0 -----------
+    roofline = None
+    stages = {}
+    if rank == 0:
+        timer = R.StageTimer()
+        R.set_stage_timer(timer)
+        d_sum = 0
+        k_prof = min(args.steps, n_views)
+        for s in range(k_prof):
+            v = (s * world + rank) % n_views
+            opt.zero_grad()
+            out = net.module(poses[v:v + 1], (H, W)) if world > 1 else net(poses[v:v + 1], (H, W))
+            d_sum += R.last_instance_count()
+            l1_loss(out, target).backward()
+        R.set_stage_timer(None)
+        tot = timer.totals_ms()
+        d_avg = d_sum / k_prof
+        stages = {k: round(t / c, 4) for k, (t, c) in tot.items()}
+        dom = max(("composite_fwd", "composite_bwd", "depth_sort", "bin_instances", "project_fwd", "build_records",
+                   "preprocess_bwd"), key=lambda k: stages.get(k, 0.0))
+        ach = algorithmic_bytes(dom, n, d_avg, H * W) / (stages[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": stages[dom], "avg_instances_D": int(d_avg),
+                    "note": "VALU/LDS-bound compositing: frac is small by construction, see DESIGN.md 4"}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import gsx_oracle as O          # checker / reported baseline only
+        O.lib()
+        pose0 = create_orbit_poses(4.0, n_views, 45.0)[10]
+        d_rgb = np.sign(np.random.default_rng(1).standard_normal((3, H, W))).astype(np.float32) / (3 * H * W)
+        t1 = time.perf_counter()
+        fw = O.forward(params, pose0, H, W, "tiled")
+        O.backward(params, pose0, H, W, fw, d_rgb, None, None, None, "tiled")
+        tc = time.perf_counter() - t1
+        cpu = {"value": round(H * W / tc / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(), "kind": "port",
+               "sample": f"1 view (orbit view 10, D={fw['D']}) of the same workload, tiled CPU restatement fwd+bwd, {tc:.2f} s; "
+                         "the reference's own dense loop cannot run at this size (16 ns*N*P, SURVEY 6)"}
+
+    if rank == 0:
+        value = world * args.steps * H * W / dt / 1e6
+        line = {
+            "metric": "fwd+bwd splat-render Mpixels/s @1M Gaussians 1024^2",
+            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, 60-view orbit (radius 4, elevation 45), "
+                                   f"one trainer step per view per GPU"
+                                   + (" (render fwd+bwd only)" if args.no_optimizer else " (fwd + L1 + bwd + clip + Adam)"),
+                       "views_per_step": world, "parallelism": f"dp{world} over views"},
+            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""Data-parallel gradient path: replaces DistributedDataParallel + NCCL of the reference
+(/root/reference/scripts/train.py:65-73,134-139; training/trainer.py:83-97) with ONE RCCL
+all-reduce over the flat 14*N gradient buffer the render backward already produces.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm; "gloo" on CPU for the
+tests).  The path shards over camera views; parameters are replicated; the only exchange step is
+the gradient average after the local backward.  There is nothing to overlap it with: every
+Gaussian's gradient is final only when the last tile of the last local view has finished.
+"""
+import torch
+import torch.distributed as dist
+
+PARAM_ORDER = ("rotations", "positions", "scales", "opacity", "features")   # layout of the flat buffers
+
+
+def shard_views(n_views, rank, world):
+    """view v -> rank v mod world."""
+    return list(range(rank, n_views, world))
+
+
+def _flat_view_of(tensors):
+    """If the tensors are consecutive views into one contiguous storage (as RenderFunction.backward
+    lays the gradients out), return that flat tensor without copying; else None."""
+    t0 = tensors[0]
+    base = t0.untyped_storage().data_ptr()
+    expect = t0.data_ptr()
+    total = 0
+    for t in tensors:
+        if not t.is_contiguous() or t.untyped_storage().data_ptr() != base or t.data_ptr() != expect:
+            return None
+        expect += t.numel() * t.element_size(); total += t.numel()
+    off = (t0.data_ptr() - base) // t0.element_size()
+    flat_all = torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage())
+    return flat_all[off:off + total]
+
+
+class DataParallelSplat(torch.nn.Module):
+    """Wraps a GaussianSplat the way the reference wraps it in DDP (`.module` holds the model so
+    trainer code written against DDP keeps working), broadcasts rank 0's parameters once
+    (trainer.py:83-87) and averages gradients with one all-reduce (DDP semantics: SUM / world).
+
+    auto_sync=True fires the all-reduce from autograd hooks as soon as all five parameter
+    gradients of a backward are final -- like DDP, the caller only calls loss.backward().
+    """
+
+    def __init__(self, module, process_group=None, auto_sync=True, broadcast=True):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._params = [getattr(module, k) for k in PARAM_ORDER]
+        self._pending = 0
+        self.last_allreduce_bytes = 0
+        if broadcast and self.world > 1:
+            self.broadcast_parameters()
+        if auto_sync and self.world > 1:
+            for p in self._params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def forward(self, camera_poses, image_size):
+        return self.module(camera_poses, image_size)
+
+    def broadcast_parameters(self, src=0):
+        flat = torch.cat([p.data.reshape(-1) for p in self._params])
+        dist.broadcast(flat, src, group=self.group)
+        off = 0
+        for p in self._params:
+            p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+
+    def _on_grad(self, _p):
+        self._pending += 1
+        if self._pending == len(self._params):
+            self._pending = 0
+            self.sync_gradients()
+
+    def sync_gradients(self):
+        """Average .grad of the five parameters over all ranks in one collective."""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self._params]
+        if any(g is None for g in grads):
+            raise RuntimeError("sync_gradients: a parameter has no gradient")
+        flat = _flat_view_of(grads)
+        packed = flat is None
+        if packed:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        self.last_allreduce_bytes = flat.numel() * flat.element_size()
+        if packed:
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+
+def reduce_metric(value, device=None, group=None):
+    """Scalar metric averaged over ranks (trainer.py:89-97)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)

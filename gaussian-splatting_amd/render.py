@@ -24,6 +24,44 @@ def _f32c(t):
     return t.contiguous()
 
 
+class StageTimer:
+    """Optional per-stage HIP-event timing (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream)."""
+    def __init__(self):
+        self.events = []          # (name, start, end)
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), n + 1)
+        return out
+
+
+_timer = None
+
+
+def set_stage_timer(t):
+    global _timer
+    _timer = t
+
+
+class _stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timer is not None:
+            self.a = torch.cuda.Event(enable_timing=True); self.a.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            b = torch.cuda.Event(enable_timing=True); b.record()
+            _timer.events.append((self.name, self.a, b))
+        return False
+
+
 class _Scratch:
     """Per-device grow-only scratch for binning (instance buffers are sized by the data)."""
     def __init__(self):
@@ -50,8 +88,9 @@ def depth_order(depth_keys):
     v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
     wsb = lib.gsx_sort_workspace_bytes(n)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    L.check(lib.gsx_sort_pairs_u32(_ptr(depth_keys), None, _ptr(k_out), _ptr(order), _ptr(k_tmp), _ptr(v_tmp),
-                                   n, 0, 32, _ptr(ws), wsb, _stream()), "gsx_sort_pairs_u32")
+    with _stage("depth_sort"):
+        L.check(lib.gsx_sort_pairs_u32(_ptr(depth_keys), None, _ptr(k_out), _ptr(order), _ptr(k_tmp), _ptr(v_tmp),
+                                       n, 0, 32, _ptr(ws), wsb, _stream()), "gsx_sort_pairs_u32")
     return order
 
 
@@ -62,8 +101,9 @@ def project(positions, scales, rotations, pose):
     depth = torch.empty(n, dtype=torch.float32, device=dev)
     cov2d = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
     keys = torch.empty(n, dtype=torch.int32, device=dev)
-    L.check(lib.gsx_project_fwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(pose), n,
-                                _ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(keys), _stream()), "gsx_project_fwd")
+    with _stage("project_fwd"):
+        L.check(lib.gsx_project_fwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(pose), n,
+                                    _ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(keys), _stream()), "gsx_project_fwd")
     return mean2d, depth, cov2d, keys
 
 
@@ -72,8 +112,9 @@ def build_records(mean2d, depth, cov2d, opacity, features, order, H, W):
     n = order.numel(); dev = order.device
     rec = torch.empty(n, L.REC_FLOATS, dtype=torch.float32, device=dev)
     tt = torch.empty(n, dtype=torch.int32, device=dev)
-    L.check(lib.gsx_build_records(_ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(opacity), _ptr(features), _ptr(order),
-                                  n, H, W, _ptr(rec), _ptr(tt), _stream()), "gsx_build_records")
+    with _stage("build_records"):
+        L.check(lib.gsx_build_records(_ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(opacity), _ptr(features), _ptr(order),
+                                      n, H, W, _ptr(rec), _ptr(tt), _stream()), "gsx_build_records")
     return rec, tt
 
 
@@ -90,8 +131,9 @@ def bin_instances(rec, tt, H, W):
         bufs = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
         wsb = lib.gsx_bin_workspace_bytes(n, cap)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        st = lib.gsx_bin_instances(_ptr(rec), _ptr(tt), n, H, W, cap, _ptr(offsets), _ptr(bufs[0]), _ptr(bufs[1]),
-                                   _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), C.byref(D), _ptr(ws), wsb, _stream())
+        with _stage("bin_instances"):
+            st = lib.gsx_bin_instances(_ptr(rec), _ptr(tt), n, H, W, cap, _ptr(offsets), _ptr(bufs[0]), _ptr(bufs[1]),
+                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), C.byref(D), _ptr(ws), wsb, _stream())
         if st == L.GSX_E_CAPACITY:
             _scratch.grow(dev, D.value)
             continue
@@ -99,7 +141,17 @@ def bin_instances(rec, tt, H, W):
         break
     else:
         raise L.GsxError(L.GSX_E_CAPACITY, "gsx_bin_instances")
+    global _last_D
+    _last_D = int(D.value)
     return offsets, bufs[0], bufs[1], ranges, int(D.value)
+
+
+_last_D = 0
+
+
+def last_instance_count():
+    """(tile, Gaussian) instance count D of the most recent binning call."""
+    return _last_D
 
 
 def composite_forward(rec, ranks_sorted, ranges, n, H, W, want_depth=True):
@@ -110,8 +162,9 @@ def composite_forward(rec, ranks_sorted, ranges, n, H, W, want_depth=True):
     dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
     state = torch.empty(1, dtype=torch.int32, device=dev)
     for p in (0, 1):
-        L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), n, H, W, p, _ptr(state),
-                                      _ptr(rgb), _ptr(alpha), _ptr(dmap), _stream()), "gsx_composite_fwd")
+        with _stage("composite_fwd" if p == 0 else "composite_fwd_exit_pass"):
+            L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), n, H, W, p, _ptr(state),
+                                          _ptr(rgb), _ptr(alpha), _ptr(dmap), _stream()), "gsx_composite_fwd")
     return rgb, alpha, dmap, state
 
 
@@ -145,9 +198,11 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
     partials = None
     if d_rgb is not None and vs.D > 0:
         partials = torch.empty(vs.D, 9, dtype=torch.float32, device=dev)
-        L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.offsets), n, vs.H, vs.W,
-                                      _ptr(vs.state), _ptr(vs.rgb), _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
-    L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features),
+        with _stage("composite_bwd"):
+            L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.offsets), n, vs.H, vs.W,
+                                          _ptr(vs.state), _ptr(vs.rgb), _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
+    with _stage("preprocess_bwd"):
+      L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features),
                                    _ptr(vs.pose), _ptr(vs.order), _ptr(vs.rec), _ptr(vs.offsets), _ptr(vs.tt),
                                    _ptr(partials), _ptr(vs.state), _ptr(d_mean2d), _ptr(d_depth), _ptr(d_cov2d),
                                    n, 1 if accumulate else 0, *[_ptr(g) for g in grads], _stream()), "gsx_preprocess_bwd")

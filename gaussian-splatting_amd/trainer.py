@@ -1,0 +1,48 @@
+"""The trainer step around the render path (caller a13 of SURVEY 8a): same sequence as
+/root/reference/training/trainer.py:133-178 -- zero_grad, forward, loss, backward,
+clip_grad_norm_, Adam step -- with the reference's five per-tensor learning rates (:49-61).
+The reference's own loss needs VGG16/LPIPS weights from the network (model/loss.py:34,39) and
+is out of scope; the loss is a callable here."""
+import torch
+
+# configs/default_config.yaml:12-16
+DEFAULT_LRS = dict(positions=1e-4, features=1e-3, scales=1e-4, rotations=1e-4, opacity=1e-3)
+
+
+def make_optimizer(model, lrs=None):
+    """Adam with one group per tensor in the reference's order (trainer.py:49-61)."""
+    lrs = dict(DEFAULT_LRS, **(lrs or {}))
+    m = model.module if hasattr(model, "module") else model
+    return torch.optim.Adam([
+        {'params': m.positions, 'lr': lrs['positions']},
+        {'params': m.features, 'lr': lrs['features']},
+        {'params': m.scales, 'lr': lrs['scales']},
+        {'params': m.rotations, 'lr': lrs['rotations']},
+        {'params': m.opacity, 'lr': lrs['opacity']},
+    ])
+
+
+def l1_loss(outputs, target):
+    return (outputs['rendered_images'] - target).abs().mean()
+
+
+def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
+    """The importable-math subset of model/loss.py:89-109: clamped MSE + scale and opacity
+    regularisers (exercises all three gradient routes into the render backward)."""
+    c = outputs['rendered_images'].clamp(1e-8, 1 - 1e-8)
+    o = outputs['opacity']
+    return ((c - target) ** 2).mean() + w_scale * torch.norm(outputs['scales'], dim=-1).mean() \
+        + w_opacity * (o * (1 - o)).mean()
+
+
+def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad_norm=0.1):
+    """One step (trainer.py:134-175).  With a DataParallelSplat model the gradient all-reduce
+    fires inside backward(); clipping then sees the averaged gradients, like DDP."""
+    optimizer.zero_grad()
+    outputs = model(camera_poses, target.shape[-2:])
+    loss = loss_fn(outputs, target)
+    loss.backward()
+    if max_grad_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    optimizer.step()
+    return loss.detach()
