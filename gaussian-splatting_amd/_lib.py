@@ -13,7 +13,7 @@ SYMBOLS = [
     "gsx_strerror", "gsx_last_hip_error", "gsx_abi_version",
     "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32",
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
-    "gsx_bin_workspace_bytes", "gsx_bin_instances",
+    "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_max_chunks",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
 ]
 
@@ -21,6 +21,8 @@ GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
 TILE = 16
+CHUNK = 256
+STATE_WORDS = 8
 
 
 class GsxError(RuntimeError):
@@ -54,13 +56,14 @@ def lib():
     L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
     L.gsx_build_records.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
     L.gsx_bin_workspace_bytes.restype = _sz; L.gsx_bin_workspace_bytes.argtypes = [_i32, _i64]
-    L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
-    L.gsx_composite_fwd.argtypes = [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]
-    L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p]
+    L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
+    L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32]
+    L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
+    L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
     L.gsx_preprocess_bwd.argtypes = [_p] * 15 + [_i32, _i32] + [_p] * 6
     for name in SYMBOLS:
         getattr(L, name)
-        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes"):
+        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name != "gsx_max_chunks":
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

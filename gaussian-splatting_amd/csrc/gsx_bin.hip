@@ -35,13 +35,18 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
     while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
-__global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, uint32_t D, int n_tiles, uint32_t* __restrict__ ranges)
+// also counts the tile's compositing chunks (GSX_CHUNK instances each); entry n_tiles is 0 so that
+// the exclusive scan of chunk_cnt[0..n_tiles] ends with the total
+__global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, uint32_t D, int n_tiles,
+                                                        uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_cnt)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t > n_tiles) return;
+    if (t == n_tiles) { chunk_cnt[t] = 0; return; }
     const uint32_t lb = lower_bound_u32(tiles_sorted, D, (uint32_t)t);
-    if (t < n_tiles) ranges[2*t] = lb;
-    if (t > 0) ranges[2*(t-1)+1] = lb;
+    const uint32_t ub = lower_bound_u32(tiles_sorted, D, (uint32_t)t + 1u);
+    ranges[2*t] = lb; ranges[2*t+1] = ub;
+    chunk_cnt[t] = (ub - lb + GSX_CHUNK - 1) / GSX_CHUNK;
 }
 
 static int tile_bits(int n_tiles) { int b = 1; while ((1 << b) < n_tiles) b++; return b; }
@@ -50,24 +55,40 @@ static int tile_bits(int n_tiles) { int b = 1; while ((1 << b) < n_tiles) b++; r
 
 using namespace gsx;
 
+// scan workspace that covers the chunk table of the largest image (65535/16)^2 tiles
+static size_t chunk_scan_ws_bytes() { return gsx_scan_workspace_bytes((int64_t)4096 * 4096 + 1); }
+
 GSX_API size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity)
 {
     size_t a = gsx_scan_workspace_bytes(N > 0 ? N : 1);
     size_t b = sort_ws_bytes_internal(capacity > 0 ? capacity : 1);
-    return 256 + (a > b ? a : b);
+    size_t c = chunk_scan_ws_bytes();
+    size_t m = a > b ? a : b;
+    return 256 + (m > c ? m : c);
+}
+
+GSX_API int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W)
+{
+    const int64_t n_tiles = (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE);
+    return D / GSX_CHUNK + (D < n_tiles ? D : n_tiles);
 }
 
 GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
                               int64_t capacity, uint32_t* offsets,
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                              uint32_t* ranges, int64_t* D_host, void* ws, size_t ws_bytes, void* stream)
+                              uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity < 0) return GSX_E_INVALID;
-    if (!ranges || !D_host || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
+    if (!ranges || !chunk_base || !D_host || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     *D_host = 0;
-    if (N == 0) { GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st)); return GSX_OK; }
+    auto empty = [&]() -> int {
+        GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st));
+        GSX_HIP(hipMemsetAsync(chunk_base, 0, (size_t)(n_tiles + 1) * 4, st));
+        return GSX_OK;
+    };
+    if (N == 0) return empty();
     if (!rec || !tiles_touched || !offsets) return GSX_E_INVALID;
     uint64_t* total_dev = (uint64_t*)ws;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
@@ -79,7 +100,7 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     *D_host = (int64_t)D;
     if (D >= 0xFFFFFFFFull) return GSX_E_RANGE;
     if ((int64_t)D > capacity) return GSX_E_CAPACITY;
-    if (D == 0) { GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st)); return GSX_OK; }
+    if (D == 0) return empty();
     if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
@@ -90,7 +111,7 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     GSX_LAUNCH_CHECK();
     s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, (int64_t)D, 0, bits, sub_ws, sub_bytes, st);
     if (s != GSX_OK) return s;
-    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, (uint32_t)D, n_tiles, ranges);
+    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, (uint32_t)D, n_tiles, ranges, chunk_base);
     GSX_LAUNCH_CHECK();
-    return GSX_OK;
+    return scan_internal(chunk_base, chunk_base, nullptr, (int64_t)n_tiles + 1, sub_ws, sub_bytes, st);
 }

@@ -1,15 +1,31 @@
-// gsx_composite.hip -- per-tile alpha compositing, forward and backward (gfx950, wave64).
+// gsx_composite.hip -- alpha compositing, forward and backward (gfx950, wave64).
 // Replaces the inner loop of _render_chunk (/root/reference/model/gaussian_splatting.py:118-148)
-// and the autograd graph recorded over it.  One 256-thread workgroup (4 wave64) per 16x16 tile;
-// the tile's depth-ordered splat records are staged through LDS in batches of 256 and every
-// lane (= pixel) walks the batch with broadcast LDS reads.
+// and the autograd graph recorded over it.
 //
-// Bound: LDS-broadcast + VALU (about 20 VALU + 1 v_exp_f32 per pixel-splat pair); HBM traffic is
-// 52 B per instance forward (4 B rank + 48 B record) plus 24 B per pixel.  No MFMA: there is no
+// Work decomposition (MI355X-first: >> 256 equal work items whatever the splats' screen
+// distribution -- the orbit views of BASELINE config 3 put 1M splats on ~400 of 4096 tiles):
+//   * a tile's depth-ordered list is cut into CHUNKS of <= GSX_CHUNK instances;
+//   * one wave64 composites one chunk for the whole 16x16 tile, 4 pixels per lane (one per 8x8
+//     quadrant), records staged through LDS 64 at a time and read back as broadcasts; a quadrant
+//     the splat's pixel box misses is skipped with a scalar branch;
+//   * compositing is associative: chunk c yields (C_loc, T_loc); a per-tile pass scans the chunks
+//     (prefix transmittance forward, colour-behind backward) and writes the image.
+// Transmittance is carried as (mantissa, exponent) so that long lists neither underflow nor lose
+// the relative accuracy the backward needs.  The backward walks each chunk back to front:
+//   T_k = T_{k+1} / (1 - alpha_k),  dL/dalpha_k = T_k (c_k.G - W_k),  W_{k-1} = alpha_k c_k.G + (1 - alpha_k) W_k
+// starting from the chunk-end state (T_end, W_end = G . colour-behind) the forward left -- no
+// subtraction of nearly equal sums anywhere.  Nine partial sums per (tile, splat) are reduced over
+// the wave with DPP and stored as ONE row per instance: no atomics, bitwise reproducible.
+//
+// Bound: VALU (about 25 VALU + 1 v_exp_f32 per pixel-splat pair forward, ~45 + reduction
+// backward); HBM traffic per instance is 52 B forward + 24 B of chunk state.  No MFMA: there is no
 // contraction on this path.
 #include "gsx_common.h"
 
 namespace gsx {
+
+constexpr int kCBatch = 64;            // records staged per LDS batch (one per lane)
+constexpr int kPixPerTile = GSX_TILE * GSX_TILE;
 
 __device__ __forceinline__ float pix_coord(int i, int steps, float step)
 {
@@ -25,96 +41,230 @@ __device__ __forceinline__ uint32_t rank_limit_from_state(const uint32_t* state,
     return (s != GSX_RANK_NONE && s + 1u < N) ? s + 1u : N;
 }
 
-struct TileGeom { int tx, ty, x, y; bool inside; float gx, gy; };
-
-__device__ __forceinline__ TileGeom tile_geom(int tile, int tw, int H, int W, float stepx, float stepy)
+// (1 - alpha), never exactly zero: an exactly opaque splat leaves 2^-30 of the light through
+// (forward and backward agree on it, so T_{k+1}/(1 - alpha_k) is always defined)
+__device__ __forceinline__ float one_minus(float al)
 {
-    TileGeom t;
-    t.tx = tile % tw; t.ty = tile / tw;
-    t.x = t.tx * GSX_TILE + (threadIdx.x & 15);
-    t.y = t.ty * GSX_TILE + (threadIdx.x >> 4);
-    t.inside = t.x < W && t.y < H;
-    t.gx = pix_coord(t.x < W ? t.x : W - 1, W, stepx);
-    t.gy = pix_coord(t.y < H ? t.y : H - 1, H, stepy);
-    return t;
+    const float f = 1.0f - al;
+    return f == 0.0f ? 9.313225746e-10f : f;
+}
+
+__device__ __forceinline__ void renorm(float& m, int& e)
+{
+    e += __builtin_amdgcn_frexp_expf(m);
+    m = __builtin_amdgcn_frexp_mantf(m);
+}
+
+struct ChunkGeom { int tile, tx, ty; uint32_t begin, end; };
+
+// chunk -> (tile, instance range).  chunk_base has n_tiles+1 entries (exclusive scan of chunks per tile).
+__device__ __forceinline__ ChunkGeom chunk_locate(const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t chunk,
+                                                  const uint32_t* __restrict__ ranges, int tw)
+{
+    int lo = 0, hi = n_tiles - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (chunk_base[mid + 1] > chunk) hi = mid; else lo = mid + 1; }
+    ChunkGeom g;
+    g.tile = lo; g.tx = lo % tw; g.ty = lo / tw;
+    g.begin = ranges[2*lo] + (chunk - chunk_base[lo]) * (uint32_t)GSX_CHUNK;
+    g.end = min(g.begin + (uint32_t)GSX_CHUNK, ranges[2*lo+1]);
+    return g;
+}
+
+// pixel p of a tile in "quadrant-major" order: k = p >> 6 picks the 8x8 quadrant, lane = p & 63
+__device__ __forceinline__ void pix_xy(int k, int lane, int tx, int ty, int& x, int& y)
+{
+    x = tx * GSX_TILE + (lane & 7) + ((k & 1) << 3);
+    y = ty * GSX_TILE + (lane >> 3) + ((k >> 1) << 3);
+}
+
+__device__ __forceinline__ float* state_ptr(float* chunk_state, uint32_t chunk, int word, int pix)
+{
+    return chunk_state + ((size_t)chunk * GSX_STATE_WORDS + word) * kPixPerTile + pix;
 }
 
 // ------------------------------------------------------------------------------------------
-// forward
+// F1: one wave per chunk, local compositing from (C = 0, T = 1)
 // ------------------------------------------------------------------------------------------
 template <bool PASS1, bool DEPTH>
-__global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
+__global__ __launch_bounds__(64) void chunk_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
-    uint32_t N, int H, int W, int tw, float stepx, float stepy, uint32_t* __restrict__ state,
+    const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t N, int H, int W, int tw, float stepx, float stepy,
+    const uint32_t* __restrict__ state, float* __restrict__ chunk_state)
+{
+    __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
+    __shared__ uint32_t s_rank[kCBatch];
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= chunk_base[n_tiles]) return;
+    uint32_t limit = N;
+    if (PASS1) { limit = rank_limit_from_state(state, N); if (limit >= N) return; }
+    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    const int lane = threadIdx.x;
+    const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
+    float gx[2], gy[2];
+    gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
+    gy[0] = pix_coord(min(y0, H - 1), H, stepy); gy[1] = pix_coord(min(y0 + 8, H - 1), H, stepy);
+    const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
+    float C0[4], C1[4], C2[4], Dm[4], m[4]; int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
+    bool stop = false;
+    for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
+        const uint32_t i = bs + lane;
+        if (i < g.end) {
+            const uint32_t r = ranks[i];
+            s_rank[lane] = r;
+            const float4* R = rec + (size_t)3 * r;
+            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = R[2];
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)kCBatch, g.end - bs);
+        for (uint32_t j = 0; j < cnt; j++) {
+            if (PASS1) { if (s_rank[j] >= limit) { stop = true; break; } }
+            const float4 a = s_a[j], b = s_b[j], c = s_c[j];
+            const uint32_t bx = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
+            const uint32_t by = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+            const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
+            const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ox = (k & 1) << 3, oy = (k >> 1) << 3;
+                if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
+                    const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float al = b.y * exp2f(q);
+                    const float w = ldexpf(m[k], e[k]) * al;
+                    C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
+                    if (DEPTH) Dm[k] += w * c.y;
+                    m[k] *= one_minus(al);
+                }
+            }
+            if ((j & 3) == 3) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        renorm(m[k], e[k]);
+        const int pix = k * 64 + lane;
+        *state_ptr(chunk_state, chunk, 0, pix) = C0[k];
+        *state_ptr(chunk_state, chunk, 1, pix) = C1[k];
+        *state_ptr(chunk_state, chunk, 2, pix) = C2[k];
+        *state_ptr(chunk_state, chunk, 3, pix) = m[k];
+        *state_ptr(chunk_state, chunk, 4, pix) = __int_as_float(e[k]);
+        *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// F2: one workgroup per tile, thread = pixel.  Forward scan over the tile's chunks (prefix
+// transmittance, image), then -- for training -- a backward scan that replaces each chunk's
+// local colour by the colour BEHIND it (per unit transmittance at the chunk's end).
+// state[1] is raised if some pixel is clearly not saturated (the global early exit cannot fire).
+// ------------------------------------------------------------------------------------------
+template <bool PASS1, bool DEPTH>
+__global__ __launch_bounds__(kBlock) void tile_combine_kernel(
+    const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state,
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
-    __shared__ float4 s_a[kBlock], s_b[kBlock], s_c[kBlock];
+    if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
+    const int tile = blockIdx.x, pix = threadIdx.x;
+    const uint32_t c0 = chunk_base[tile], c1 = chunk_base[tile + 1];
+    int x, y; pix_xy(pix >> 6, pix & 63, tile % tw, tile / tw, x, y);
+    const bool inside = x < W && y < H;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, m = 1.f; int e = 0;
+    for (uint32_t c = c0; c < c1; c++) {
+        const float Tv = ldexpf(m, e);
+        C0 += Tv * *state_ptr(chunk_state, c, 0, pix);
+        C1 += Tv * *state_ptr(chunk_state, c, 1, pix);
+        C2 += Tv * *state_ptr(chunk_state, c, 2, pix);
+        if (DEPTH) Dm += Tv * *state_ptr(chunk_state, c, 5, pix);
+        m *= *state_ptr(chunk_state, c, 3, pix);
+        e += __float_as_int(*state_ptr(chunk_state, c, 4, pix));
+        renorm(m, e);
+        if (need_bwd) { *state_ptr(chunk_state, c, 6, pix) = m; *state_ptr(chunk_state, c, 7, pix) = __int_as_float(e); }
+    }
+    const float A = 1.0f - ldexpf(m, e);
+    if (inside) {
+        const size_t P = (size_t)H * W, p = (size_t)y * W + x;
+        rgb[p] = C0; rgb[P + p] = C1; rgb[2*P + p] = C2;
+        alpha[p] = A;
+        if (DEPTH) depth_map[p] = Dm;
+    }
+    if (!PASS1) {
+        // a pixel at least 1e-5 below the threshold is unsaturated in any arithmetic
+        const bool unsat = inside && !(A > GSX_SAT_ALPHA - 1e-5f);
+        if (__syncthreads_or(unsat) && threadIdx.x == 0) atomicOr(state + 1, 1u);
+    }
+    if (need_bwd) {
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f;
+        for (uint32_t c = c1; c-- > c0; ) {
+            const float l0 = *state_ptr(chunk_state, c, 0, pix), l1 = *state_ptr(chunk_state, c, 1, pix), l2 = *state_ptr(chunk_state, c, 2, pix);
+            const float Tl = ldexpf(*state_ptr(chunk_state, c, 3, pix), __float_as_int(*state_ptr(chunk_state, c, 4, pix)));
+            *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
+            B0 = l0 + Tl * B0; B1 = l1 + Tl * B1; B2 = l2 + Tl * B2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// F3: exact global early-exit index (gaussian_splatting.py:147).  Runs only when F2 found every
+// pixel saturated.  One workgroup per tile walks the list with the REFERENCE's arithmetic
+// (A += (1-A)*alpha, :144) and records, per pixel, the first rank after which A > 0.99; the
+// global maximum is the exit index.  A tile stops as soon as all its pixels have saturated.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
+    const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
+    int H, int W, int tw, float stepx, float stepy, uint32_t* __restrict__ state)
+{
+    __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
     __shared__ uint32_t s_red[4];
+    if (state[1] != 0u) {                    // some pixel never saturates: no early exit
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(state, GSX_RANK_NONE);
+        return;
+    }
     const int tile = blockIdx.x;
     const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
-    uint32_t limit = N;
-    if (PASS1) {
-        limit = rank_limit_from_state(state, N);
-        if (limit >= N) return;                              // early exit did not fire: pass 0 image stands
-        if (end == begin || ranks[end-1] < limit) return;    // this tile holds nothing beyond the exit rank
-    }
-    const TileGeom t = tile_geom(tile, tw, H, W, stepx, stepy);
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f, Dm = 0.f;
-    uint32_t sat = GSX_RANK_NONE;
+    const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
+    const bool inside = x < W && y < H;
+    const float gx = pix_coord(min(x, W - 1), W, stepx), gy = pix_coord(min(y, H - 1), H, stepy);
+    float A = 0.f;
+    uint32_t sat = inside ? GSX_RANK_NONE : 0u;        // pixels outside the image do not vote
     for (uint32_t start = begin; start < end; start += kBlock) {
         const uint32_t i = start + threadIdx.x;
         if (i < end) {
             const uint32_t r = ranks[i];
             s_rank[threadIdx.x] = r;
             const float4* R = rec + (size_t)3 * r;
-            s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1]; s_c[threadIdx.x] = R[2];
+            s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1];
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)kBlock, end - start);
-        bool stop = false;
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t r = s_rank[j];
-            if (PASS1 && r >= limit) { stop = true; break; }
-            const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const float dx = t.gx - a.x, dy = t.gy - a.y;
+            const float4 a = s_a[j], b = s_b[j];
+            const float dx = gx - a.x, dy = gy - a.y;
             const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
             const float am = b.y * exp2f(q);
-            const float T = 1.0f - A;
-            C0 = C0 + T * (b.z * am); C1 = C1 + T * (b.w * am); C2 = C2 + T * (c.x * am);
-            if (DEPTH) Dm = Dm + T * (c.y * am);
-            A = A + T * am;
-            if (!PASS1) { if (sat == GSX_RANK_NONE && A > GSX_SAT_ALPHA) sat = r; }
+            A = A + (1.0f - A) * am;
+            if (sat == GSX_RANK_NONE && A > GSX_SAT_ALPHA) sat = s_rank[j];
         }
-        if (stop) break;
-        __syncthreads();
+        if (__syncthreads_and(sat != GSX_RANK_NONE)) break;
     }
-    if (t.inside) {
-        const size_t P = (size_t)H * W, p = (size_t)t.y * W + t.x;
-        rgb[p] = C0; rgb[P + p] = C1; rgb[2*P + p] = C2;
-        alpha[p] = A;
-        if (DEPTH) depth_map[p] = Dm;
-    }
-    if (!PASS1) {
-        // max over the image of the per-pixel saturation rank; pixels outside the image do not vote
-        uint32_t v = t.inside ? sat : 0u;
+    uint32_t v = sat;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicMax(state, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
-    }
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(state, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
 }
 
 // ------------------------------------------------------------------------------------------
-// backward.  Front-to-back again (same order, same arithmetic as the forward, so T_k and the
-// colour prefix are reproduced exactly and never divided out of a product that may underflow):
-//   dL/dalpha_k = T_k (c_k . G) - S_k / (1 - alpha_k),   S_k = G . (C_final - C_prefix_k)
-// Nine partial sums per (tile, splat) are reduced over the 16-lane rows with DPP, over the
-// workgroup with LDS float adds, and stored as ONE row per instance (no global atomics).
+// B1: backward, one wave per chunk, back to front
 // ------------------------------------------------------------------------------------------
-constexpr int kBwdBatch = 128;     // splats staged per batch in the backward (LDS: 6 KB records + 18 KB partial sums)
-
 // wave64 total of v, valid in lane 63: 16-lane row sums, then row_bcast15 / row_bcast31 (fixed order -> deterministic)
 __device__ __forceinline__ float wave_sum_lane63(float v)
 {
@@ -124,95 +274,109 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
+__global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
-    const uint32_t* __restrict__ offsets, uint32_t N, int H, int W, int tw, float stepx, float stepy,
-    const uint32_t* __restrict__ state, const float* __restrict__ rgb, const float* __restrict__ d_rgb,
-    float* __restrict__ partials)
+    const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
+    uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
+    const float* __restrict__ chunk_state, const float* __restrict__ d_rgb, float* __restrict__ partials)
 {
-    __shared__ float4 s_a[kBwdBatch], s_b[kBwdBatch], s_c[kBwdBatch];
-    __shared__ uint32_t s_rank[kBwdBatch], s_slot[kBwdBatch];
-    __shared__ float s_part[4][kBwdBatch][9];          // one slab per wave: no LDS atomics, fixed summation order
-    const int tile = blockIdx.x;
-    const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
-    if (begin == end) return;
+    __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
+    __shared__ uint32_t s_slot[kCBatch];
+    __shared__ float s_out[kCBatch][9];
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= chunk_base[n_tiles]) return;
     const uint32_t limit = rank_limit_from_state(state, N);
-    const TileGeom t = tile_geom(tile, tw, H, W, stepx, stepy);
-    const size_t P = (size_t)H * W, p = (size_t)t.y * W + t.x;
-    float G0 = 0.f, G1 = 0.f, G2 = 0.f, S = 0.f;
-    if (t.inside) {
-        G0 = d_rgb[p]; G1 = d_rgb[P + p]; G2 = d_rgb[2*P + p];
-        S = G0 * rgb[p] + G1 * rgb[P + p] + G2 * rgb[2*P + p];
+    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    // instances of this chunk that were composited: ranks ascend, keep those below the exit rank
+    uint32_t eff_end = g.end;
+    if (limit < N) {
+        uint32_t lo = g.begin, hi = g.end;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (ranks[mid] < limit) lo = mid + 1; else hi = mid; }
+        eff_end = lo;
     }
-    float A = 0.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t start = begin; start < end; start += kBwdBatch) {
-        const uint32_t i = start + threadIdx.x;
-        if (threadIdx.x < kBwdBatch && i < end) {
-            const uint32_t r = ranks[i];
-            s_rank[threadIdx.x] = r;
+    if (eff_end == g.begin) return;
+    const int lane = threadIdx.x;
+    const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
+    float gx[2], gy[2];
+    gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
+    gy[0] = pix_coord(min(y0, H - 1), H, stepy); gy[1] = pix_coord(min(y0 + 8, H - 1), H, stepy);
+    const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
+    const size_t P = (size_t)H * W;
+    float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x0 + ((k & 1) << 3), y = y0 + ((k >> 1) << 3);
+        G0[k] = G1[k] = G2[k] = 0.f;
+        if (x < W && y < H) { const size_t p = (size_t)y * W + x; G0[k] = d_rgb[p]; G1[k] = d_rgb[P + p]; G2[k] = d_rgb[2*P + p]; }
+        const int pix = k * 64 + lane;
+        const float* cs = chunk_state + (size_t)chunk * GSX_STATE_WORDS * kPixPerTile + pix;
+        Wb[k] = G0[k] * cs[0 * kPixPerTile] + G1[k] * cs[1 * kPixPerTile] + G2[k] * cs[2 * kPixPerTile];
+        m[k] = cs[6 * kPixPerTile]; e[k] = __float_as_int(cs[7 * kPixPerTile]);
+    }
+    const uint32_t nb = (eff_end - g.begin + kCBatch - 1) / kCBatch;
+    for (uint32_t bi = nb; bi-- > 0; ) {
+        const uint32_t bs = g.begin + bi * kCBatch;
+        const uint32_t cnt = min((uint32_t)kCBatch, eff_end - bs);
+        if ((uint32_t)lane < cnt) {
+            const uint32_t r = ranks[bs + lane];
             const float4* R = rec + (size_t)3 * r;
             const float4 c = R[2];
-            s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1]; s_c[threadIdx.x] = c;
+            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
             const uint32_t bx = __float_as_uint(c.z), by = __float_as_uint(c.w);
-            const int x0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, x1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;
-            const int y0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
-            s_slot[threadIdx.x] = offsets[r] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
+            const int tx0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, tx1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;
+            const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
+            s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
         }
         __syncthreads();
-        const uint32_t cnt = min((uint32_t)kBwdBatch, end - start);
-        uint32_t done = cnt;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t r = s_rank[j];
-            if (r >= limit) { done = j; break; }
+        for (uint32_t j = cnt; j-- > 0; ) {
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const float dx = t.gx - a.x, dy = t.gy - a.y;
-            const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-            const float am = b.y * exp2f(q);
-            const float T = 1.0f - A;
-            const float w = T * am;
-            A = A + w;
-            const float cG = b.z * G0 + b.w * G1 + c.x * G2;
-            S = S - w * cG;
-            const float om = 1.0f - am;
-            const float inv = (om != 0.0f) ? __frcp_rn(om) : 0.0f;
-            float dq = (T * cG - S * inv) * am * GSX_LN2;      // dL/dq'   (alpha = o * exp2(q'))
-            float wv = w;
-            if (!t.inside) { dq = 0.f; wv = 0.f; }
-            const float v0 = wave_sum_lane63(dq);
-            const float v1 = wave_sum_lane63(dq * dx);
-            const float v2 = wave_sum_lane63(dq * dy);
-            const float v3 = wave_sum_lane63(dq * dx * dx);
-            const float v4 = wave_sum_lane63(dq * dx * dy);
-            const float v5 = wave_sum_lane63(dq * dy * dy);
-            const float v6 = wave_sum_lane63(wv * G0);
-            const float v7 = wave_sum_lane63(wv * G1);
-            const float v8 = wave_sum_lane63(wv * G2);
+            const uint32_t bx = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
+            const uint32_t by = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+            const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
+            const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ox = (k & 1) << 3, oy = (k >> 1) << 3;
+                if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
+                    const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float al = b.y * exp2f(q);
+                    const float f = one_minus(al);
+                    m[k] *= __builtin_amdgcn_rcpf(f);                 // T_k = T_{k+1} / (1 - alpha_k)
+                    const float Tv = ldexpf(m[k], e[k]);
+                    const float cG = b.z * G0[k] + b.w * G1[k] + c.x * G2[k];
+                    const float dal = Tv * (cG - Wb[k]);              // dL/dalpha_k
+                    Wb[k] = al * cG + f * Wb[k];
+                    const float dq = dal * al * GSX_LN2;              // dL/dq'  (alpha = o * exp2(q'))
+                    const float wv = Tv * al;
+                    s0 += dq; s1 += dq * dx; s2 += dq * dy;
+                    s3 += dq * dx * dx; s4 += dq * dx * dy; s5 += dq * dy * dy;
+                    s6 += wv * G0[k]; s7 += wv * G1[k]; s8 += wv * G2[k];
+                }
+            }
+            if ((j & 3) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
+            }
+            s0 = wave_sum_lane63(s0); s1 = wave_sum_lane63(s1); s2 = wave_sum_lane63(s2);
+            s3 = wave_sum_lane63(s3); s4 = wave_sum_lane63(s4); s5 = wave_sum_lane63(s5);
+            s6 = wave_sum_lane63(s6); s7 = wave_sum_lane63(s7); s8 = wave_sum_lane63(s8);
             if (lane == 63) {
-                float* dst = s_part[wave][j];
-                dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4;
-                dst[5] = v5; dst[6] = v6; dst[7] = v7; dst[8] = v8;
+                // row: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
+                float* o = s_out[j];
+                o[0] = -(2.0f * a.z * s1 + a.w * s2);
+                o[1] = -(a.w * s1 + 2.0f * b.x * s2);
+                o[2] = s3; o[3] = s4; o[4] = s5;
+                o[5] = s0 / (b.y * GSX_LN2);
+                o[6] = s6; o[7] = s7; o[8] = s8;
             }
         }
         __syncthreads();
-        // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
-        for (uint32_t idx = threadIdx.x; idx < done * 9u; idx += kBlock) {
+        for (uint32_t idx = lane; idx < cnt * 9u; idx += 64) {
             const uint32_t j = idx / 9u, c = idx - j * 9u;
-            float sp[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) sp[k] = 0.f;
-            // only the sums this component needs, waves added in a fixed order
-            auto tot = [&](int k) { return ((s_part[0][j][k] + s_part[1][j][k]) + s_part[2][j][k]) + s_part[3][j][k]; };
-            float out;
-            if (c == 0)      out = -(2.0f * s_a[j].z * tot(1) + s_a[j].w * tot(2));
-            else if (c == 1) out = -(s_a[j].w * tot(1) + 2.0f * s_b[j].x * tot(2));
-            else if (c <= 4) out = tot((int)c + 1);
-            else if (c == 5) out = tot(0) / (s_b[j].y * GSX_LN2);
-            else             out = tot((int)c);
-            (void)sp;
-            partials[(size_t)s_slot[j] * 9u + c] = out;
+            partials[(size_t)s_slot[j] * 9u + c] = s_out[j][c];
         }
-        if (done < cnt) break;
         __syncthreads();
     }
 }
@@ -224,42 +388,57 @@ using namespace gsx;
 static inline float lin_step(int steps) { return steps > 1 ? (1.0f - (-1.0f)) / (float)(steps - 1) : 0.0f; }
 
 GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
-                              int32_t N, int32_t H, int32_t W, int32_t pass, uint32_t* state,
+                              const uint32_t* chunk_base, int32_t N, int32_t H, int32_t W,
+                              int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,
                               float* rgb, float* alpha, float* depth_map, void* stream)
 {
-    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || (pass != 0 && pass != 1)) return GSX_E_INVALID;
-    if (!ranges || !state || !rgb || !alpha) return GSX_E_INVALID;
-    if (N > 0 && (!rec || !ranks_sorted)) return GSX_E_INVALID;
+    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
+    if (!ranges || !chunk_base || !state || !rgb || !alpha) return GSX_E_INVALID;
+    if (max_chunks > 0 && (!rec || !ranks_sorted || !chunk_state)) return GSX_E_INVALID;
+    if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
+    const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     const float sx = lin_step(W), sy = lin_step(H);
-    const dim3 grid((unsigned)(tw * th)), block(kBlock);
     const float4* r4 = (const float4*)rec;
-    if (pass == 0) {
-        GSX_HIP(hipMemsetAsync(state, 0, 4, st));
-        if (depth_map) composite_fwd_kernel<false, true><<<grid, block, 0, st>>>(r4, ranks_sorted, ranges, (uint32_t)N, H, W, tw, sx, sy, state, rgb, alpha, depth_map);
-        else           composite_fwd_kernel<false, false><<<grid, block, 0, st>>>(r4, ranks_sorted, ranges, (uint32_t)N, H, W, tw, sx, sy, state, rgb, alpha, depth_map);
+    const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
+    GSX_HIP(hipMemsetAsync(state, 0, 16, st));
+    // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
+    if (depth_map) {
+        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
     } else {
-        if (depth_map) composite_fwd_kernel<true, true><<<grid, block, 0, st>>>(r4, ranks_sorted, ranges, (uint32_t)N, H, W, tw, sx, sy, state, rgb, alpha, depth_map);
-        else           composite_fwd_kernel<true, false><<<grid, block, 0, st>>>(r4, ranks_sorted, ranges, (uint32_t)N, H, W, tw, sx, sy, state, rgb, alpha, depth_map);
+        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+    }
+    saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
+    if (max_chunks > 0) {
+        if (depth_map) {
+            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+        } else {
+            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+        }
     }
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
 
 GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
-                              const uint32_t* offsets, int32_t N, int32_t H, int32_t W, const uint32_t* state,
-                              const float* rgb, const float* d_rgb, float* partials, void* stream)
+                              const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                              int64_t max_chunks, const float* chunk_state, const uint32_t* state,
+                              const float* d_rgb, float* partials, void* stream)
 {
-    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return GSX_E_INVALID;
-    if (N == 0) return GSX_OK;
-    if (!rec || !ranks_sorted || !ranges || !offsets || !state || !rgb || !d_rgb || !partials) return GSX_E_INVALID;
+    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
+    if (N == 0 || max_chunks == 0) return GSX_OK;
+    if (!rec || !ranks_sorted || !ranges || !chunk_base || !offsets || !chunk_state || !state || !d_rgb || !partials) return GSX_E_INVALID;
+    if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
-    composite_bwd_kernel<<<dim3((unsigned)(tw * th)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        (const float4*)rec, ranks_sorted, ranges, offsets, (uint32_t)N, H, W, tw, lin_step(W), lin_step(H),
-        state, rgb, d_rgb, partials);
+    chunk_bwd_kernel<<<dim3((unsigned)max_chunks), dim3(64), 0, (hipStream_t)stream>>>(
+        (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
+        lin_step(W), lin_step(H), state, chunk_state, d_rgb, partials);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -276,4 +455,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 1; }
+GSX_API int gsx_abi_version(void) { return 2; }

@@ -125,6 +125,7 @@ def bin_instances(rec, tt, H, W):
     tw, th = (W + L.TILE - 1) // L.TILE, (H + L.TILE - 1) // L.TILE
     offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     ranges = torch.empty(tw * th, 2, dtype=torch.int32, device=dev)
+    chunk_base = torch.empty(tw * th + 1, dtype=torch.int32, device=dev)
     D = C.c_int64(0)
     for _attempt in range(2):
         cap = _scratch.cap(dev, n)
@@ -133,7 +134,7 @@ def bin_instances(rec, tt, H, W):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         with _stage("bin_instances"):
             st = lib.gsx_bin_instances(_ptr(rec), _ptr(tt), n, H, W, cap, _ptr(offsets), _ptr(bufs[0]), _ptr(bufs[1]),
-                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), C.byref(D), _ptr(ws), wsb, _stream())
+                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), C.byref(D), _ptr(ws), wsb, _stream())
         if st == L.GSX_E_CAPACITY:
             _scratch.grow(dev, D.value)
             continue
@@ -143,7 +144,7 @@ def bin_instances(rec, tt, H, W):
         raise L.GsxError(L.GSX_E_CAPACITY, "gsx_bin_instances")
     global _last_D
     _last_D = int(D.value)
-    return offsets, bufs[0], bufs[1], ranges, int(D.value)
+    return offsets, bufs[0], bufs[1], ranges, chunk_base, int(D.value)
 
 
 _last_D = 0
@@ -154,26 +155,29 @@ def last_instance_count():
     return _last_D
 
 
-def composite_forward(rec, ranks_sorted, ranges, n, H, W, want_depth=True):
+def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_depth=True, need_bwd=True):
     lib = L.lib()
     dev = rec.device
     rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
-    state = torch.empty(1, dtype=torch.int32, device=dev)
-    for p in (0, 1):
-        with _stage("composite_fwd" if p == 0 else "composite_fwd_exit_pass"):
-            L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), n, H, W, p, _ptr(state),
-                                          _ptr(rgb), _ptr(alpha), _ptr(dmap), _stream()), "gsx_composite_fwd")
-    return rgb, alpha, dmap, state
+    state = torch.empty(4, dtype=torch.int32, device=dev)
+    max_chunks = int(lib.gsx_max_chunks(D, H, W))
+    chunk_state = torch.empty(max(max_chunks, 1) * L.STATE_WORDS * 256, dtype=torch.float32, device=dev)
+    with _stage("composite_fwd"):
+        L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), _ptr(chunk_base), n, H, W,
+                                      max_chunks, _ptr(chunk_state), 1 if need_bwd else 0, _ptr(state),
+                                      _ptr(rgb), _ptr(alpha), _ptr(dmap), _stream()), "gsx_composite_fwd")
+    return rgb, alpha, dmap, state, chunk_state, max_chunks
 
 
 class ViewState:
     """Everything one view's backward needs (kept alive by the autograd node)."""
-    __slots__ = ("pose", "order", "rec", "tt", "offsets", "ranks", "ranges", "state", "rgb", "D", "H", "W")
+    __slots__ = ("pose", "order", "rec", "tt", "offsets", "ranks", "ranges", "chunk_base", "chunk_state", "max_chunks",
+                 "state", "D", "H", "W")
 
 
-def forward_view(params, pose, H, W, order=None, want_depth=True):
+def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True):
     """One view. params = (positions, scales, rotations, opacity, features), fp32 contiguous CUDA."""
     positions, scales, rotations, opacity, features = params
     n = positions.shape[0]
@@ -181,11 +185,13 @@ def forward_view(params, pose, H, W, order=None, want_depth=True):
     if order is None:
         order = depth_order(keys)
     rec, tt = build_records(mean2d, depth, cov2d, opacity, features, order, H, W)
-    offsets, tiles, ranks, ranges, D = bin_instances(rec, tt, H, W)
-    rgb, alpha, dmap, state = composite_forward(rec, ranks, ranges, n, H, W, want_depth)
+    offsets, tiles, ranks, ranges, chunk_base, D = bin_instances(rec, tt, H, W)
+    rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, D,
+                                                                          want_depth, need_bwd)
     vs = ViewState()
     vs.pose, vs.order, vs.rec, vs.tt, vs.offsets = pose, order, rec, tt, offsets
-    vs.ranks, vs.ranges, vs.state, vs.rgb, vs.D, vs.H, vs.W = ranks, ranges, state, rgb, D, H, W
+    vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = ranks, ranges, chunk_base, chunk_state, max_chunks
+    vs.state, vs.D, vs.H, vs.W = state, D, H, W
     vs_extra = dict(tiles=tiles)
     return (rgb, alpha, dmap, mean2d, depth, cov2d), vs, vs_extra
 
@@ -199,8 +205,9 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
     if d_rgb is not None and vs.D > 0:
         partials = torch.empty(vs.D, 9, dtype=torch.float32, device=dev)
         with _stage("composite_bwd"):
-            L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.offsets), n, vs.H, vs.W,
-                                          _ptr(vs.state), _ptr(vs.rgb), _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
+            L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.chunk_base), _ptr(vs.offsets),
+                                          n, vs.H, vs.W, vs.max_chunks, _ptr(vs.chunk_state), _ptr(vs.state),
+                                          _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
     with _stage("preprocess_bwd"):
       L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features),
                                    _ptr(vs.pose), _ptr(vs.order), _ptr(vs.rec), _ptr(vs.offsets), _ptr(vs.tt),
@@ -222,10 +229,11 @@ class RenderFunction(torch.autograd.Function):
         params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
         poses = _f32c(poses.detach())
         B = poses.shape[0]
+        need_bwd = any(ctx.needs_input_grad[:5])
         outs, views = [], []
         order = None
         for b in range(B):
-            o, vs, _ = forward_view(params, poses[b], H, W, order=order)
+            o, vs, _ = forward_view(params, poses[b], H, W, order=order, need_bwd=need_bwd)
             if order is None:
                 order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
             outs.append(o); views.append(vs)
@@ -233,7 +241,7 @@ class RenderFunction(torch.autograd.Function):
         rgb = torch.stack([o[0] for o in outs]); alpha = torch.stack([o[1] for o in outs])
         dmap = torch.stack([o[2] for o in outs]); mean2d = torch.stack([o[3] for o in outs])
         depth = torch.stack([o[4] for o in outs]); cov2d = torch.stack([o[5] for o in outs])
-        state = torch.cat([vs.state for vs in views])
+        state = torch.stack([vs.state[0] for vs in views])
         ctx.mark_non_differentiable(alpha, dmap, state)
         return rgb, mean2d, depth, cov2d, alpha, dmap, state
 

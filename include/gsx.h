@@ -73,42 +73,53 @@ int gsx_build_records(const float* mean2d, const float* depth, const float* cov2
                       int32_t N, int32_t H, int32_t W, float* rec, uint32_t* tiles_touched, void* stream);
 
 /* ---- binning: scan tiles_touched -> offsets, emit (tile, rank) instances, sort them by tile
- * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), and cut tile
- * ranges.  Synchronises `stream` once to read the instance count D back.
+ * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), cut tile
+ * ranges and the chunk table.  Synchronises `stream` once to read the instance count D back.
  *   capacity     : elements available in each of the four instance buffers
  *   offsets      : N u32 (exclusive scan of tiles_touched, rank order)
  *   tiles_sorted / ranks_sorted : results (D valid elements)
  *   tiles_tmp / ranks_tmp       : scratch of the same capacity
  *   ranges       : n_tiles x 2 u32, ranges[t] = [lower_bound(t), lower_bound(t+1)) into the sorted arrays
+ *   chunk_base   : n_tiles + 1 u32, exclusive scan of ceil(len(t) / GSX_CHUNK); last entry = chunk count
  *   *D_host      : instance count (also on GSX_E_CAPACITY, so the caller can grow and retry)
  * ws: gsx_bin_workspace_bytes(N, capacity). */
 size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity);
 int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
                       int64_t capacity, uint32_t* offsets,
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                      uint32_t* ranges, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
+                      uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
+/* upper bound on the chunk count for D instances: D / GSX_CHUNK + min(D, n_tiles).  The caller sizes
+ * chunk_state with it: max_chunks * GSX_STATE_WORDS * 256 floats. */
+int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
 
-/* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  One 256-thread
- * workgroup per 16x16 tile; splat records staged through LDS in batches of 256.
- *   state[0] (u32, in/out): saturation rank.  gsx_composite_fwd with pass = 0 composites every
- *       instance and writes max over pixels of the first rank after which accumulated alpha
- *       > 0.99 (GSX_RANK_NONE if some pixel never saturates) -- the reference's global early
- *       exit index (:147).  With pass = 1 it reads state[0] and re-composites, only if the exit
- *       fired, the tiles that hold ranks beyond it, stopping at the exit rank.
+/* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  A tile's depth-ordered
+ * list is cut into chunks of GSX_CHUNK instances; one wave64 composites one chunk for the whole
+ * 16x16 tile (4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
+ * the chunks (compositing is associative) and writes the image.  Enqueues, in order: chunk pass,
+ * combine pass, exact early-exit search (only does work when every pixel saturated: the
+ * reference's global exit, :147), and a second chunk + combine pass that only does work when the
+ * exit fired before the last Gaussian.
+ *   state (4 x u32, out): state[0] = exit rank k* (GSX_RANK_NONE: no exit), state[1] = 1 if some
+ *       pixel is unsaturated.  Ranks 0..k* are composited.
+ *   chunk_state: max_chunks * GSX_STATE_WORDS * 256 floats; with need_bwd = 1 it is left holding
+ *       what gsx_composite_bwd needs (per chunk and pixel: colour behind the chunk, transmittance
+ *       at its end).
  *   rgb (3,H,W), alpha (H,W) accumulated alpha, depth_map (H,W) or NULL. */
 int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
-                      int32_t N, int32_t H, int32_t W, int32_t pass, uint32_t* state,
+                      const uint32_t* chunk_base, int32_t N, int32_t H, int32_t W,
+                      int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,
                       float* rgb, float* alpha, float* depth_map, void* stream);
 
-/* ---- backward of compositing (the reference relies on autograd over :124-144).  Walks each
- * tile's list front to back again, reduces the nine per-splat partial sums over the wavefront
- * (DPP) and the workgroup (LDS) and stores ONE row per (tile, rank) instance at
+/* ---- backward of compositing (the reference relies on autograd over :124-144).  One wave64 per
+ * chunk walks it back to front from the chunk-end state the forward left, reduces the nine
+ * per-splat partial sums over the wavefront (DPP) and stores ONE row per (tile, rank) instance at
  * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
  * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
- *   partials: capacity >= D rows of 9 floats.  state[0]: as left by the forward. */
+ *   partials: >= D rows of 9 floats. */
 int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
-                      const uint32_t* offsets, int32_t N, int32_t H, int32_t W, const uint32_t* state,
-                      const float* rgb, const float* d_rgb, float* partials, void* stream);
+                      const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                      int64_t max_chunks, const float* chunk_state, const uint32_t* state,
+                      const float* d_rgb, float* partials, void* stream);
 
 /* ---- backward of records + projection: sums each splat's partial rows, then chains through
  * the 2x2 inverse, J*Sigma3*J^T, R(q)diag(s^2)R(q)^T, quaternion normalisation and the

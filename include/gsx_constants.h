@@ -33,6 +33,15 @@
  * rectangle is [lo >> 4, (hi >> 4) + 1).  Images are limited to 65535 pixels per side. */
 #define GSX_REC_FLOATS 12
 
+/* compositing work item: at most GSX_CHUNK consecutive instances of one tile's depth-ordered list,
+ * composited by one wave64 (4 pixels per lane); chunk results are combined per tile afterwards
+ * (alpha compositing is associative), so the load is balanced however the splats fall on screen */
+#define GSX_CHUNK 256
+/* floats per pixel per chunk in the chunk-state buffer:
+ *  0..2 local colour (later: colour behind the chunk)  3,4 local transmittance (mantissa, exponent)
+ *  5 local depth  6,7 transmittance at the chunk's end (mantissa, exponent) */
+#define GSX_STATE_WORDS 8
+
 /* "no saturation" marker for the per-pixel saturation rank */
 #define GSX_RANK_NONE 0xFFFFFFFFu
 

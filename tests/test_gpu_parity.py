@@ -40,9 +40,9 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
     mean2d, depth, cov2d, keys = R.project(P[0], P[1], P[2], pose_t)
     order_t = R.depth_order(keys) if order is None else torch.from_numpy(order.astype(np.int32)).to(dev)
     rec, tt = R.build_records(mean2d, depth, cov2d, P[3], P[4], order_t, H, W)
-    offsets, tiles, ranks, ranges, D = R.bin_instances(rec, tt, H, W)
+    offsets, tiles, ranks, ranges, chunk_base, D = R.bin_instances(rec, tt, H, W)
     n = P[0].shape[0]
-    rgb, alpha, dmap, state = R.composite_forward(rec, ranks, ranges, n, H, W, True)
+    rgb, alpha, dmap, state, chunk_state, max_chunks = R.composite_forward(rec, ranks, ranges, chunk_base, n, H, W, D, True, True)
     torch.cuda.synchronize()
     s = int(_u32(state)[0])
     out = dict(mean2d=mean2d.cpu().numpy(), depth=depth.cpu().numpy(), cov2d=cov2d.cpu().numpy(), keys=_u32(keys),
@@ -50,8 +50,12 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
                tiles=_u32(tiles)[:D], ranks=_u32(ranks)[:D], ranges=_u32(ranges), rgb=rgb.cpu().numpy(),
                alpha=alpha.cpu().numpy()[0], depth_map=dmap.cpu().numpy()[0],
                n_composited=(s + 1 if (s != 0xFFFFFFFF and s + 1 < n) else n))
+    cb = _u32(chunk_base)
+    lens = (out["ranges"][:, 1] - out["ranges"][:, 0]).astype(np.int64)
+    assert np.array_equal(cb, np.concatenate([[0], np.cumsum((lens + 255) // 256)]).astype(np.uint32)), "chunk table"
+    assert int(cb[-1]) <= max_chunks
     out["_t"] = dict(P=P, pose=pose_t, order=order_t, rec=rec, tt=tt, offsets=offsets, ranks=ranks, ranges=ranges,
-                     state=state, rgb=rgb, D=D)
+                     chunk_base=chunk_base, chunk_state=chunk_state, max_chunks=max_chunks, state=state, D=D)
     return out
 
 
@@ -60,7 +64,8 @@ def gpu_backward(gp, H, W, d_rgb, d_mean2d=None, d_depth=None, d_cov=None):
     t = gp["_t"]; dev = t["rec"].device
     vs = R.ViewState()
     vs.pose, vs.order, vs.rec, vs.tt, vs.offsets = t["pose"], t["order"], t["rec"], t["tt"], t["offsets"]
-    vs.ranks, vs.ranges, vs.state, vs.rgb, vs.D, vs.H, vs.W = t["ranks"], t["ranges"], t["state"], t["rgb"], t["D"], H, W
+    vs.ranks, vs.ranges, vs.state, vs.D, vs.H, vs.W = t["ranks"], t["ranges"], t["state"], t["D"], H, W
+    vs.chunk_base, vs.chunk_state, vs.max_chunks = t["chunk_base"], t["chunk_state"], t["max_chunks"]
     grads = [torch.empty_like(p) for p in t["P"]]
     cv = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     R.backward_view(t["P"], vs, cv(d_rgb), cv(d_mean2d), cv(d_depth), cv(d_cov), grads, accumulate=False)
@@ -192,10 +197,7 @@ def test_synthetic_vs_oracle(dev, O, case):
     n = params["positions"].shape[0]
     d_m = rng.standard_normal((n, 2)).astype(np.float32); d_d = rng.standard_normal(n).astype(np.float32)
     d_c = rng.standard_normal((n, 2, 2)).astype(np.float32)
-    # KNOWN LIMIT (round 1): with opacity > 1 some pixels have alpha within 1e-4 of 1 and the
-    # front-to-back backward divides a cancellation-limited suffix by (1 - alpha); the bound is
-    # loosened for that adversarial scene only until the backward walks back to front.
-    tol = 1e-2 if case == "opacity_out_of_range" else GRAD_RTOL
+    tol = GRAD_RTOL      # also for opacity outside [0,1] (alpha crossing 1): the back-to-front backward has no cancellation
     g = gpu_backward(gp, H, W, d_rgb, d_m, d_d, d_c)
     go = O.backward(params, pose, H, W, fw, d_rgb, d_m, d_d, d_c, "tiled")
     for k in PARAMS:
