@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
                 if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                    const float al = b.y * exp2f(q);
+                    const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float w = ldexpf(m[k], e[k]) * al;
                     C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
                     if (DEPTH) Dm[k] += w * c.y;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             const float4 a = s_a[j], b = s_b[j];
             const float dx = gx - a.x, dy = gy - a.y;
             const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-            const float am = b.y * exp2f(q);
+            const float am = b.y * __builtin_amdgcn_exp2f(q);
             A = A + (1.0f - A) * am;
             if (sat == GSX_RANK_NONE && A > GSX_SAT_ALPHA) sat = s_rank[j];
         }
@@ -274,6 +274,37 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
     return v;
 }
 
+// Reduce EIGHT per-lane values over the wave at once (reduce-scatter): v_permlane32_swap /
+// v_permlane16_swap halve the register count at distances 32 and 16, a DPP rotate + select at
+// distance 8, then three DPP adds inside each 8-lane group: 18 VALU instead of 48.
+// On return lane l holds the wave total of value (l >> 3).  Fixed order -> deterministic.
+// (inline asm: ROCm 7.2's __builtin_amdgcn_permlane{32,16}_swap returns the FIRST register for both
+// results; the s_nop 1 on each side are the VALU wait states hipcc would have placed around it)
+__device__ __forceinline__ float swap_add32(float a, float b)
+{
+    // lanes 32..63 of a <-> lanes 0..31 of b
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap_add16(float a, float b)
+{
+    // 16-lane rows 1,3 of a <-> rows 0,2 of b
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float wave_reduce8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, bool hi8)
+{
+    const float u0 = swap_add32(v0, v4), u1 = swap_add32(v1, v5), u2 = swap_add32(v2, v6), u3 = swap_add32(v3, v7);
+    const float w0 = swap_add16(u0, u2), w1 = swap_add16(u1, u3);
+    const float t0 = w0 + dpp_mov<0x128>(w0);        // row_ror:8
+    const float t1 = w1 + dpp_mov<0x128>(w1);
+    float z = hi8 ? t1 : t0;
+    z += dpp_mov<0x141>(z);                           // row_half_mirror: lane i <-> 7-i inside each 8
+    z += dpp_mov<0xB1>(z);                            // quad_perm [1,0,3,2]
+    z += dpp_mov<0x4E>(z);                            // quad_perm [2,3,0,1]
+    return z;
+}
+
 __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
-    __shared__ float s_out[kCBatch][9];
+    __shared__ float s_out[kCBatch][9];              // raw sums: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy, w*G0..2
     const uint32_t chunk = blockIdx.x;
     if (chunk >= chunk_base[n_tiles]) return;
     const uint32_t limit = rank_limit_from_state(state, N);
@@ -341,7 +372,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
                 if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                    const float al = b.y * exp2f(q);
+                    const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float f = one_minus(al);
                     m[k] *= __builtin_amdgcn_rcpf(f);                 // T_k = T_{k+1} / (1 - alpha_k)
                     const float Tv = ldexpf(m[k], e[k]);
@@ -359,23 +390,23 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
-            s0 = wave_sum_lane63(s0); s1 = wave_sum_lane63(s1); s2 = wave_sum_lane63(s2);
-            s3 = wave_sum_lane63(s3); s4 = wave_sum_lane63(s4); s5 = wave_sum_lane63(s5);
-            s6 = wave_sum_lane63(s6); s7 = wave_sum_lane63(s7); s8 = wave_sum_lane63(s8);
-            if (lane == 63) {
-                // row: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
-                float* o = s_out[j];
-                o[0] = -(2.0f * a.z * s1 + a.w * s2);
-                o[1] = -(a.w * s1 + 2.0f * b.x * s2);
-                o[2] = s3; o[3] = s4; o[4] = s5;
-                o[5] = s0 / (b.y * GSX_LN2);
-                o[6] = s6; o[7] = s7; o[8] = s8;
-            }
+            const float z = wave_reduce8(s0, s1, s2, s3, s4, s5, s6, s7, (lane & 8) != 0);
+            s8 = wave_sum_lane63(s8);
+            if ((lane & 7) == 0) s_out[j][lane >> 3] = z;
+            if (lane == 63) s_out[j][8] = s8;
         }
         __syncthreads();
+        // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
         for (uint32_t idx = lane; idx < cnt * 9u; idx += 64) {
             const uint32_t j = idx / 9u, c = idx - j * 9u;
-            partials[(size_t)s_slot[j] * 9u + c] = s_out[j][c];
+            const float* sp = s_out[j];
+            float out;
+            if (c == 0)      out = -(2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
+            else if (c == 1) out = -(s_a[j].w * sp[1] + 2.0f * s_b[j].x * sp[2]);
+            else if (c <= 4) out = sp[c + 1];
+            else if (c == 5) out = sp[0] / (s_b[j].y * GSX_LN2);
+            else             out = sp[c];
+            partials[(size_t)s_slot[j] * 9u + c] = out;
         }
         __syncthreads();
     }
