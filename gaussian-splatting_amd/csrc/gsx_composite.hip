@@ -55,6 +55,21 @@ __device__ __forceinline__ void renorm(float& m, int& e)
     m = __builtin_amdgcn_frexp_mantf(m);
 }
 
+// 4-bit mask of the tile's 8x8 quadrants (bit k: x half k&1, y half k>>1) the splat's pixel box touches.
+// Computed once per record by the staging lane and kept in the LDS copy of the record, so the
+// per-splat loop spends one v_readfirstlane + four scalar bit tests instead of ~40 scalar compares
+// (the CU's single scalar ALU was the bottleneck of the first chunked version).
+__device__ __forceinline__ uint32_t quad_mask(float box_x, float box_y, int qx, int qy)
+{
+    const uint32_t bx = __float_as_uint(box_x), by = __float_as_uint(box_y);
+    const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
+    const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
+    const uint32_t mx = (uint32_t)(xlo <= 7 && xhi >= 0) | ((uint32_t)(xlo <= 15 && xhi >= 8) << 1);
+    const uint32_t my = (uint32_t)(ylo <= 7 && yhi >= 0) | ((uint32_t)(ylo <= 15 && yhi >= 8) << 1);
+    // bit k = mx[k&1] & my[k>>1]
+    return ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);
+}
+
 struct ChunkGeom { int tile, tx, ty; uint32_t begin, end; };
 
 // chunk -> (tile, instance range).  chunk_base has n_tiles+1 entries (exclusive scan of chunks per tile).
@@ -114,21 +129,19 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             const uint32_t r = ranks[i];
             s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
-            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = R[2];
+            float4 c = R[2];
+            c.z = __uint_as_float(quad_mask(c.z, c.w, qx, qy));
+            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)kCBatch, g.end - bs);
         for (uint32_t j = 0; j < cnt; j++) {
             if (PASS1) { if (s_rank[j] >= limit) { stop = true; break; } }
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t bx = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
-            const uint32_t by = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
-            const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
+            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int ox = (k & 1) << 3, oy = (k >> 1) << 3;
-                if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
+                if (mk & (1u << k)) {
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
@@ -351,25 +364,22 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         if ((uint32_t)lane < cnt) {
             const uint32_t r = ranks[bs + lane];
             const float4* R = rec + (size_t)3 * r;
-            const float4 c = R[2];
-            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
+            float4 c = R[2];
             const uint32_t bx = __float_as_uint(c.z), by = __float_as_uint(c.w);
             const int tx0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, tx1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;
             const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
+            c.z = __uint_as_float(quad_mask(c.z, c.w, qx, qy));
+            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
         }
         __syncthreads();
         for (uint32_t j = cnt; j-- > 0; ) {
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t bx = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
-            const uint32_t by = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
-            const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
+            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int ox = (k & 1) << 3, oy = (k >> 1) << 3;
-                if (xlo <= ox + 7 && xhi >= ox && ylo <= oy + 7 && yhi >= oy) {
+                if (mk & (1u << k)) {
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
