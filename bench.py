@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--config", default="c3", help="scene config (c2/c3/c4/c5); the metric is quoted on c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time render fwd+bwd(+all-reduce) only")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +82,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev)
     net = DataParallelSplat(model) if world > 1 else model
-    opt = make_optimizer(net)
+    opt = make_optimizer(net, fused_clip_norm=None if args.torch_optimizer else 0.1)
     n_views = 60
     poses = torch.from_numpy(create_orbit_poses(4.0, n_views, 45.0)).to(dev)      # README.md:129-137
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -163,7 +165,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, 60-view orbit (radius 4, elevation 45), "
                                    f"one trainer step per view per GPU"
-                                   + (" (render fwd+bwd only)" if args.no_optimizer else " (fwd + L1 + bwd + clip + Adam)"),
+                                   + (" (render fwd+bwd only)" if args.no_optimizer else (" (fwd + L1 + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
+                                      else " (fwd + L1 + bwd + fused clip_grad_norm+Adam)")),
                        "views_per_step": world, "parallelism": f"dp{world} over views"},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
         }

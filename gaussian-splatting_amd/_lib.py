@@ -15,6 +15,7 @@ SYMBOLS = [
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
     "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_max_chunks",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
+    "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
 ]
 
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
@@ -61,6 +62,9 @@ def lib():
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
     L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
     L.gsx_preprocess_bwd.argtypes = [_p] * 15 + [_i32, _i32] + [_p] * 6
+    L.gsx_clip_adam_workspace_bytes.restype = _sz
+    L.gsx_clip_adam_step.argtypes = [_i32, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64, C.c_float,
+                                     _i32, _p, _sz, _p]
     for name in SYMBOLS:
         getattr(L, name)
         if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name != "gsx_max_chunks":

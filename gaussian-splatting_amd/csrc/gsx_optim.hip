@@ -1,0 +1,129 @@
+// gsx_optim.hip -- fused clip_grad_norm_ + Adam step over the (up to 8) parameter tensors of the
+// splat model: the step right after the gradient all-reduce in the reference's trainer
+// (/root/reference/training/trainer.py:169-175: torch.nn.utils.clip_grad_norm_(params, 0.1) then
+// torch.optim.Adam.step() with five per-tensor learning rates, :49-61).  SURVEY 8f row N4.
+// Three launches instead of ~25 foreach kernels; HBM-bound: 4 B read for the norm + 28 B
+// read/written per element for the update.  Arithmetic follows torch's foreach Adam operation by
+// operation (lerp, mul+addcmul, sqrt/div/add, addcdiv); compiled with -ffp-contract=off.
+#include "gsx_common.h"
+
+namespace gsx {
+
+constexpr int kMaxTensors = 8;
+constexpr int kNormBlocks = 1024;
+
+struct AdamArgs {
+    float* p[kMaxTensors]; float* g[kMaxTensors]; float* m[kMaxTensors]; float* v[kMaxTensors];
+    long long begin[kMaxTensors + 1];      // prefix offsets in the virtual concatenation
+    float neg_step_size[kMaxTensors];      // -lr / (1 - beta1^t)
+    int n_tensors;
+};
+
+__device__ __forceinline__ int find_tensor(const AdamArgs& a, long long i)
+{
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxTensors; k++) if (k < a.n_tensors && i >= a.begin[k]) t = k;
+    return t;
+}
+
+// partial sums of squares over contiguous slices of the virtual concatenation (fixed slicing -> deterministic)
+__global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __restrict__ partials)
+{
+    __shared__ double s_w[4];
+    const long long total = a.begin[a.n_tensors];
+    const long long per = (total + kNormBlocks - 1) / kNormBlocks;
+    const long long lo = (long long)blockIdx.x * per, hi = min(lo + per, total);
+    double s = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const int t = find_tensor(a, i);
+        const float x = a.g[t][i - a.begin[t]];
+        s += (double)x * (double)x;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// out[0] = total_norm, out[1] = clip coefficient = min(1, max_norm / (total_norm + 1e-6))
+__global__ __launch_bounds__(kBlock) void clip_coef_kernel(const double* __restrict__ partials, float max_norm, float* __restrict__ out)
+{
+    __shared__ double s_v[kBlock];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < kNormBlocks; i += kBlock) s += partials[i];
+    s_v[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock / 2; d > 0; d >>= 1) { if (threadIdx.x < d) s_v[threadIdx.x] += s_v[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(s_v[0]);
+        float coef = max_norm / (norm + 1e-6f);
+        out[0] = norm;
+        out[1] = coef < 1.0f ? coef : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const float* __restrict__ coef_ptr, int write_clipped_grad,
+                                                      float beta1, float beta2, float eps, float bc2_sqrt)
+{
+    const long long total = a.begin[a.n_tensors];
+    const float coef = coef_ptr ? coef_ptr[1] : 1.0f;
+    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int t = find_tensor(a, i);
+        const long long j = i - a.begin[t];
+        float g = a.g[t][j];
+        if (coef_ptr) { g = g * coef; if (write_clipped_grad) a.g[t][j] = g; }
+        float m = a.m[t][j], v = a.v[t][j];
+        m = m + w1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * beta2;                           // exp_avg_sq.mul_(beta2)
+        v = v + (w2 * g) * g;                    //           .addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        a.m[t][j] = m; a.v[t][j] = v;
+        a.p[t][j] = a.p[t][j] + a.neg_step_size[t] * (m / denom);   // param.addcdiv_(exp_avg, denom, value = -step_size)
+    }
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+GSX_API size_t gsx_clip_adam_workspace_bytes(void) { return (size_t)kNormBlocks * 8 + 256; }
+
+GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, float* const* grads_host,
+                               float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                               const int64_t* numel_host, const float* lr_host,
+                               float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                               int32_t write_clipped_grad, void* ws, size_t ws_bytes, void* stream)
+{
+    if (n_tensors <= 0 || n_tensors > kMaxTensors || step <= 0) return GSX_E_INVALID;
+    if (!params_host || !grads_host || !exp_avg_host || !exp_avg_sq_host || !numel_host || !lr_host) return GSX_E_INVALID;
+    if (max_grad_norm > 0.0f && (!ws || ws_bytes < gsx_clip_adam_workspace_bytes())) return GSX_E_INVALID;
+    AdamArgs a;
+    a.n_tensors = n_tensors; a.begin[0] = 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int t = 0; t < kMaxTensors; t++) {
+        const bool on = t < n_tensors;
+        if (on && (!params_host[t] || !grads_host[t] || !exp_avg_host[t] || !exp_avg_sq_host[t] || numel_host[t] < 0)) return GSX_E_INVALID;
+        a.p[t] = on ? params_host[t] : nullptr; a.g[t] = on ? grads_host[t] : nullptr;
+        a.m[t] = on ? exp_avg_host[t] : nullptr; a.v[t] = on ? exp_avg_sq_host[t] : nullptr;
+        a.begin[t + 1] = a.begin[t] + (on ? numel_host[t] : 0);
+        a.neg_step_size[t] = on ? (float)(-(double)lr_host[t] / bc1) : 0.0f;
+    }
+    const long long total = a.begin[n_tensors];
+    if (total == 0) return GSX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = nullptr;
+    if (max_grad_norm > 0.0f) {
+        double* partials = (double*)ws;
+        coef = (float*)((char*)ws + (size_t)kNormBlocks * 8);
+        sumsq_kernel<<<dim3(kNormBlocks), dim3(kBlock), 0, st>>>(a, partials);
+        clip_coef_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(partials, max_grad_norm, coef);
+    }
+    const long long blocks = ceil_div(total, kBlock);
+    adam_kernel<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, st>>>(
+        a, coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
+    GSX_LAUNCH_CHECK();
+    return GSX_OK;
+}

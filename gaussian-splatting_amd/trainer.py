@@ -9,10 +9,21 @@ import torch
 DEFAULT_LRS = dict(positions=1e-4, features=1e-3, scales=1e-4, rotations=1e-4, opacity=1e-3)
 
 
-def make_optimizer(model, lrs=None):
-    """Adam with one group per tensor in the reference's order (trainer.py:49-61)."""
+def make_optimizer(model, lrs=None, fused_clip_norm=None):
+    """Adam with one group per tensor in the reference's order (trainer.py:49-61).
+    fused_clip_norm = max_grad_norm selects the fused HIP clip+Adam step (optim.FusedClipAdam);
+    train_step then skips its own clip_grad_norm_ call."""
     lrs = dict(DEFAULT_LRS, **(lrs or {}))
     m = model.module if hasattr(model, "module") else model
+    if fused_clip_norm is not None:
+        from .optim import FusedClipAdam
+        return FusedClipAdam([
+            {'params': m.positions, 'lr': lrs['positions']},
+            {'params': m.features, 'lr': lrs['features']},
+            {'params': m.scales, 'lr': lrs['scales']},
+            {'params': m.rotations, 'lr': lrs['rotations']},
+            {'params': m.opacity, 'lr': lrs['opacity']},
+        ], max_grad_norm=fused_clip_norm)
     return torch.optim.Adam([
         {'params': m.positions, 'lr': lrs['positions']},
         {'params': m.features, 'lr': lrs['features']},
@@ -42,7 +53,7 @@ def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad
     outputs = model(camera_poses, target.shape[-2:])
     loss = loss_fn(outputs, target)
     loss.backward()
-    if max_grad_norm > 0:
+    if max_grad_norm > 0 and not hasattr(optimizer, "max_grad_norm"):      # the fused optimizer clips inside step()
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
     return loss.detach()

@@ -135,6 +135,21 @@ int gsx_preprocess_bwd(const float* positions, const float* scales, const float*
                        float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
                        float* g_features, void* stream);
 
+/* ---- SURVEY 8f row N4 (the step right after the gradient exchange): fused
+ * torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.Adam.step() over up to 8
+ * parameter tensors with per-tensor learning rates (training/trainer.py:49-61,169-175).
+ * *_host arguments are HOST arrays (length n_tensors) of DEVICE pointers / sizes / learning rates.
+ * step >= 1 is the Adam step count AFTER this update (bias corrections use it).  With
+ * max_grad_norm <= 0 no clipping is done and ws may be NULL.  ws (device): gsx_clip_adam_workspace_bytes();
+ * after the call ((float*)((char*)ws + 8192))[0] holds the total gradient norm, [1] the clip coefficient.
+ * write_clipped_grad = 1 also scales the gradients in place, as clip_grad_norm_ does. */
+size_t gsx_clip_adam_workspace_bytes(void);
+int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, float* const* grads_host,
+                       float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                       const int64_t* numel_host, const float* lr_host,
+                       float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                       int32_t write_clipped_grad, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
