@@ -50,18 +50,18 @@ def lib():
     L.gsx_strerror.restype = C.c_char_p; L.gsx_strerror.argtypes = [C.c_int]
     L.gsx_last_hip_error.restype = C.c_int
     L.gsx_abi_version.restype = C.c_int
-    L.gsx_project_fwd.argtypes = [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]
+    L.gsx_project_fwd.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]
     L.gsx_sort_workspace_bytes.restype = _sz; L.gsx_sort_workspace_bytes.argtypes = [_i64]
     L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _sz, _p]
     L.gsx_scan_workspace_bytes.restype = _sz; L.gsx_scan_workspace_bytes.argtypes = [_i64]
     L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
-    L.gsx_build_records.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p]
     L.gsx_bin_workspace_bytes.restype = _sz; L.gsx_bin_workspace_bytes.argtypes = [_i32, _i64]
     L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
     L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
-    L.gsx_preprocess_bwd.argtypes = [_p] * 15 + [_i32, _i32] + [_p] * 6
+    L.gsx_preprocess_bwd.argtypes = [_p] * 12 + [_i32, _i32] + [_p] * 6
     L.gsx_clip_adam_workspace_bytes.restype = _sz
     L.gsx_clip_adam_step.argtypes = [_i32, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64, C.c_float,
                                      _i32, _p, _sz, _p]

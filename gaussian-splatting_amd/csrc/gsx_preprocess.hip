@@ -89,9 +89,11 @@ __device__ __forceinline__ float inv2x2(float a, float b, float c, float d, floa
 }
 
 __global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ scl,
-                                                             const float* __restrict__ rot, const float* __restrict__ pose, int N,
+                                                             const float* __restrict__ rot, const float* __restrict__ opacity,
+                                                             const float* __restrict__ features, const float* __restrict__ pose, int N,
                                                              float* __restrict__ mean2d, float* __restrict__ depth,
-                                                             float* __restrict__ cov2d, uint32_t* __restrict__ key)
+                                                             float* __restrict__ cov2d, uint32_t* __restrict__ key,
+                                                             float4* __restrict__ pre)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
@@ -107,21 +109,27 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __rest
     depth[i] = o.depth;
     reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
     key[i] = depth_key(o.depth);
+    // packed copy of everything build_records needs: ONE 48-byte row to gather per Gaussian instead of
+    // five scattered lines (mean2d, depth, cov2d, opacity, features)
+    float4* P = pre + (size_t)3 * i;
+    P[0] = make_float4(o.mx, o.my, o.cov[0], o.cov[1]);
+    P[1] = make_float4(o.cov[2], o.cov[3], o.depth, opacity[i]);
+    P[2] = make_float4(features[3*i], features[3*i+1], features[3*i+2], 0.0f);
 }
 
-__global__ __launch_bounds__(kBlock) void build_records_kernel(const float* __restrict__ mean2d, const float* __restrict__ depth,
-                                                               const float* __restrict__ cov2d, const float* __restrict__ opacity,
-                                                               const float* __restrict__ features, const uint32_t* __restrict__ order,
-                                                               int N, int H, int W, float* __restrict__ rec, uint32_t* __restrict__ tiles_touched)
+__global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
+                                                               int N, int H, int W, float* __restrict__ rec,
+                                                               uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= N) return;
     const uint32_t g = order[r];
-    const float2 mu = reinterpret_cast<const float2*>(mean2d)[g];
-    const float4 cv = reinterpret_cast<const float4*>(cov2d)[g];
-    const float a = cv.x + GSX_COV_EPS, b = cv.y, c = cv.z, d = cv.w + GSX_COV_EPS;
+    rank_of[g] = (uint32_t)r;
+    const float4 p0 = pre[(size_t)3 * g], p1 = pre[(size_t)3 * g + 1], p2 = pre[(size_t)3 * g + 2];
+    const float2 mu = make_float2(p0.x, p0.y);
+    const float a = p0.z + GSX_COV_EPS, b = p0.w, c = p1.x, d = p1.y + GSX_COV_EPS;
     float m[4]; const float det = inv2x2(a, b, c, d, m);
-    const float op = opacity[g];
+    const float op = p1.w;
     // footprint box (bit-exact contract with oracle footprint())
     uint32_t ob = __float_as_uint(op) & 0x7fffffffu;
     const int e = (int)(ob >> 23) - 127;
@@ -149,29 +157,31 @@ __global__ __launch_bounds__(kBlock) void build_records_kernel(const float* __re
     const uint32_t bx = (uint32_t)xlo | ((uint32_t)xhi << 16), by = (uint32_t)ylo | ((uint32_t)yhi << 16);
     float4* R = reinterpret_cast<float4*>(rec) + (size_t)3 * r;
     R[0] = make_float4(mu.x, mu.y, m[0] * GSX_NEG_HALF_LOG2E, (m[1] + m[2]) * GSX_NEG_HALF_LOG2E);
-    R[1] = make_float4(m[3] * GSX_NEG_HALF_LOG2E, op, features[3*g], features[3*g+1]);
-    R[2] = make_float4(features[3*g+2], depth[g], __uint_as_float(bx), __uint_as_float(by));
+    R[1] = make_float4(m[3] * GSX_NEG_HALF_LOG2E, op, p2.x, p2.y);
+    R[2] = make_float4(p2.z, p1.z, __uint_as_float(bx), __uint_as_float(by));
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: thread per rank.  Sums the splat's partial rows in a fixed order, then chain rule.
+// backward: thread per GAUSSIAN (parameters, upstream gradients and outputs are coalesced; only the
+// splat's offset/count and its partial rows are gathered through rank_of).  Sums the partial rows in
+// a fixed order, then chain rule.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float* __restrict__ pos, const float* __restrict__ scl, const float* __restrict__ rot,
-    const float* __restrict__ pose, const uint32_t* __restrict__ order, const float* __restrict__ rec,
+    const float* __restrict__ pose, const uint32_t* __restrict__ rank_of,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
     const float* __restrict__ partials, const uint32_t* __restrict__ state,
     const float* __restrict__ d_mean2d, const float* __restrict__ d_depth, const float* __restrict__ d_cov2d,
     int N, int accumulate,
     float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea)
 {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= N) return;
-    const uint32_t g = order[r];
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= N) return;
+    const uint32_t r = rank_of[g];
     float D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t limit = (uint32_t)N;
     if (state) { const uint32_t s = state[0]; if (s != GSX_RANK_NONE && s + 1u < (uint32_t)N) limit = s + 1u; }
-    if (partials && (uint32_t)r < limit) {
+    if (partials && r < limit) {
         const uint32_t o0 = offsets[r], tt = tiles_touched[r];
         for (uint32_t t = 0; t < tt; t++) {
             const float* row = partials + (size_t)9 * (o0 + t);
@@ -188,8 +198,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float q[4] = { qv.x, qv.y, qv.z, qv.w };
     Proj o; project_one(p, s, q, M, o);
     // D: 0 dmu_x 1 dmu_y 2 dk00 3 dkb 4 dk11 5 d(opacity) 6..8 d(colour)
-    const float op = rec[(size_t)GSX_REC_FLOATS * r + 5];
-    (void)op;
     // conic -> covariance: dSigma = -M^T dM M^T, dM = c0 * [[D2, D3],[D3, D4]]
     const float a = o.cov[0] + GSX_COV_EPS, b = o.cov[1], c = o.cov[2], d = o.cov[3] + GSX_COV_EPS;
     float mi[4]; inv2x2(a, b, c, d, mi);
@@ -283,53 +291,51 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
 
 using namespace gsx;
 
-GSX_API int gsx_project_fwd(const float* positions, const float* scales, const float* rotations, const float* pose, int32_t N,
-                            float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, void* stream)
+GSX_API int gsx_project_fwd(const float* positions, const float* scales, const float* rotations,
+                            const float* opacity, const float* features, const float* pose, int32_t N,
+                            float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, float* pre, void* stream)
 {
     if (N < 0) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
-    if (!positions || !scales || !rotations || !pose || !mean2d || !depth || !cov2d || !depth_key) return GSX_E_INVALID;
-    if (((uintptr_t)rotations | (uintptr_t)cov2d) & 15u) return GSX_E_INVALID;
+    if (!positions || !scales || !rotations || !opacity || !features || !pose || !mean2d || !depth || !cov2d || !depth_key || !pre) return GSX_E_INVALID;
+    if (((uintptr_t)rotations | (uintptr_t)cov2d | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
     if ((uintptr_t)mean2d & 7u) return GSX_E_INVALID;
     project_fwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        positions, scales, rotations, pose, N, mean2d, depth, cov2d, depth_key);
+        positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d, depth_key, (float4*)pre);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
 
-GSX_API int gsx_build_records(const float* mean2d, const float* depth, const float* cov2d, const float* opacity,
-                              const float* features, const uint32_t* order, int32_t N, int32_t H, int32_t W,
-                              float* rec, uint32_t* tiles_touched, void* stream)
+GSX_API int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
+                              float* rec, uint32_t* tiles_touched, uint32_t* rank_of, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
-    if (!mean2d || !depth || !cov2d || !opacity || !features || !order || !rec || !tiles_touched) return GSX_E_INVALID;
-    if (((uintptr_t)rec | (uintptr_t)cov2d) & 15u) return GSX_E_INVALID;
+    if (!pre || !order || !rec || !tiles_touched || !rank_of) return GSX_E_INVALID;
+    if (((uintptr_t)rec | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
     build_records_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        mean2d, depth, cov2d, opacity, features, order, N, H, W, rec, tiles_touched);
+        (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
 
 GSX_API int gsx_preprocess_bwd(const float* positions, const float* scales, const float* rotations,
-                               const float* opacity, const float* features, const float* pose,
-                               const uint32_t* order, const float* rec, const uint32_t* offsets,
+                               const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
                                const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                                const float* d_mean2d, const float* d_depth, const float* d_cov2d,
                                int32_t N, int32_t accumulate,
                                float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
                                float* g_features, void* stream)
 {
-    (void)opacity; (void)features;
     if (N < 0) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
-    if (!positions || !scales || !rotations || !pose || !order || !rec) return GSX_E_INVALID;
+    if (!positions || !scales || !rotations || !pose || !rank_of) return GSX_E_INVALID;
     if (partials && (!offsets || !tiles_touched)) return GSX_E_INVALID;
     if (!g_positions || !g_scales || !g_rotations || !g_opacity || !g_features) return GSX_E_INVALID;
     if (((uintptr_t)rotations | (uintptr_t)g_rotations) & 15u) return GSX_E_INVALID;
     if (d_cov2d && ((uintptr_t)d_cov2d & 15u)) return GSX_E_INVALID;
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        positions, scales, rotations, pose, order, rec, offsets, tiles_touched, partials, state,
+        positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
         d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features);
     GSX_LAUNCH_CHECK();
     return GSX_OK;

@@ -43,17 +43,19 @@ class DataParallelSplat(torch.nn.Module):
     gradients of a backward are final -- like DDP, the caller only calls loss.backward().
     """
 
-    def __init__(self, module, process_group=None, auto_sync=True, broadcast=True):
+    def __init__(self, module, process_group=None, auto_sync=True, broadcast=True, force_collectives=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())   # world 1: rehearsal only
         self._params = [getattr(module, k) for k in PARAM_ORDER]
         self._pending = 0
         self.last_allreduce_bytes = 0
-        if broadcast and self.world > 1:
+        self.last_sync_was_flat = None
+        if broadcast and self.active:
             self.broadcast_parameters()
-        if auto_sync and self.world > 1:
+        if auto_sync and self.active:
             for p in self._params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -75,13 +77,14 @@ class DataParallelSplat(torch.nn.Module):
 
     def sync_gradients(self):
         """Average .grad of the five parameters over all ranks in one collective."""
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in self._params]
         if any(g is None for g in grads):
             raise RuntimeError("sync_gradients: a parameter has no gradient")
         flat = _flat_view_of(grads)
         packed = flat is None
+        self.last_sync_was_flat = not packed
         if packed:
             flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -94,28 +94,30 @@ def depth_order(depth_keys):
     return order
 
 
-def project(positions, scales, rotations, pose):
+def project(positions, scales, rotations, opacity, features, pose):
     lib = L.lib()
     n = positions.shape[0]; dev = positions.device
     mean2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
     depth = torch.empty(n, dtype=torch.float32, device=dev)
     cov2d = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
     keys = torch.empty(n, dtype=torch.int32, device=dev)
+    pre = torch.empty(n, L.REC_FLOATS, dtype=torch.float32, device=dev)
     with _stage("project_fwd"):
-        L.check(lib.gsx_project_fwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(pose), n,
-                                    _ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(keys), _stream()), "gsx_project_fwd")
-    return mean2d, depth, cov2d, keys
+        L.check(lib.gsx_project_fwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features), _ptr(pose), n,
+                                    _ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(keys), _ptr(pre), _stream()), "gsx_project_fwd")
+    return mean2d, depth, cov2d, keys, pre
 
 
-def build_records(mean2d, depth, cov2d, opacity, features, order, H, W):
+def build_records(pre, order, H, W):
     lib = L.lib()
     n = order.numel(); dev = order.device
     rec = torch.empty(n, L.REC_FLOATS, dtype=torch.float32, device=dev)
     tt = torch.empty(n, dtype=torch.int32, device=dev)
+    rank_of = torch.empty(n, dtype=torch.int32, device=dev)
     with _stage("build_records"):
-        L.check(lib.gsx_build_records(_ptr(mean2d), _ptr(depth), _ptr(cov2d), _ptr(opacity), _ptr(features), _ptr(order),
-                                      n, H, W, _ptr(rec), _ptr(tt), _stream()), "gsx_build_records")
-    return rec, tt
+        L.check(lib.gsx_build_records(_ptr(pre), _ptr(order), n, H, W, _ptr(rec), _ptr(tt), _ptr(rank_of), _stream()),
+                "gsx_build_records")
+    return rec, tt, rank_of
 
 
 def bin_instances(rec, tt, H, W):
@@ -173,7 +175,7 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
 
 class ViewState:
     """Everything one view's backward needs (kept alive by the autograd node)."""
-    __slots__ = ("pose", "order", "rec", "tt", "offsets", "ranks", "ranges", "chunk_base", "chunk_state", "max_chunks",
+    __slots__ = ("pose", "order", "rank_of", "rec", "tt", "offsets", "ranks", "ranges", "chunk_base", "chunk_state", "max_chunks",
                  "state", "D", "H", "W")
 
 
@@ -181,15 +183,15 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
     """One view. params = (positions, scales, rotations, opacity, features), fp32 contiguous CUDA."""
     positions, scales, rotations, opacity, features = params
     n = positions.shape[0]
-    mean2d, depth, cov2d, keys = project(positions, scales, rotations, pose)
+    mean2d, depth, cov2d, keys, pre = project(positions, scales, rotations, opacity, features, pose)
     if order is None:
         order = depth_order(keys)
-    rec, tt = build_records(mean2d, depth, cov2d, opacity, features, order, H, W)
+    rec, tt, rank_of = build_records(pre, order, H, W)
     offsets, tiles, ranks, ranges, chunk_base, D = bin_instances(rec, tt, H, W)
     rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, D,
                                                                           want_depth, need_bwd)
     vs = ViewState()
-    vs.pose, vs.order, vs.rec, vs.tt, vs.offsets = pose, order, rec, tt, offsets
+    vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, order, rank_of, rec, tt, offsets
     vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = ranks, ranges, chunk_base, chunk_state, max_chunks
     vs.state, vs.D, vs.H, vs.W = state, D, H, W
     vs_extra = dict(tiles=tiles)
@@ -209,8 +211,8 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
                                           n, vs.H, vs.W, vs.max_chunks, _ptr(vs.chunk_state), _ptr(vs.state),
                                           _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
     with _stage("preprocess_bwd"):
-      L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations), _ptr(opacity), _ptr(features),
-                                   _ptr(vs.pose), _ptr(vs.order), _ptr(vs.rec), _ptr(vs.offsets), _ptr(vs.tt),
+      L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations),
+                                   _ptr(vs.pose), _ptr(vs.rank_of), _ptr(vs.offsets), _ptr(vs.tt),
                                    _ptr(partials), _ptr(vs.state), _ptr(d_mean2d), _ptr(d_depth), _ptr(d_cov2d),
                                    n, 1 if accumulate else 0, *[_ptr(g) for g in grads], _stream()), "gsx_preprocess_bwd")
 

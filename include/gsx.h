@@ -43,10 +43,13 @@ int gsx_abi_version(void);
  * One thread per Gaussian.  Outputs are the reference's returned tensors for ONE view:
  *   mean2d (N,2) = 'positions', depth (N) = 'depths', cov2d (N,2,2) = 'scales',
  * plus depth_key (N) u32: ascending-unsigned order == descending depth (the order
- * torch.argsort(depths, descending=True) produces, :198), -0 folded onto +0. */
+ * torch.argsort(depths, descending=True) produces, :198), -0 folded onto +0.
+ * pre (N x 12 floats): packed copy (mean2d, cov2d, depth, opacity, colour) that gsx_build_records gathers
+ * as one 48-byte row per Gaussian. */
 int gsx_project_fwd(const float* positions, const float* scales, const float* rotations,
+                    const float* opacity, const float* features,
                     const float* pose /* 16 floats, row-major 4x4 */, int32_t N,
-                    float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, void* stream);
+                    float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, float* pre, void* stream);
 
 /* ---- device LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit),
  * stable.  values_in == NULL means values are 0..n-1.  Result lands in keys_out/values_out;
@@ -67,10 +70,10 @@ int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* total_de
 /* ---- rank-ordered splat records: replaces the per-Gaussian gathers and torch.inverse of
  * _render_chunk (:110-115, :128-130) and adds the footprint rectangle (no counterpart in the
  * reference: it evaluates every Gaussian at every pixel).  order[r] = Gaussian composited r-th.
- * rec: N x GSX_REC_FLOATS floats (layout: gsx_constants.h); tiles_touched: N. */
-int gsx_build_records(const float* mean2d, const float* depth, const float* cov2d,
-                      const float* opacity, const float* features, const uint32_t* order,
-                      int32_t N, int32_t H, int32_t W, float* rec, uint32_t* tiles_touched, void* stream);
+ * pre: from gsx_project_fwd.  rec: N x GSX_REC_FLOATS floats (layout: gsx_constants.h);
+ * tiles_touched: N (rank order); rank_of: N, inverse of order (rank_of[order[r]] = r). */
+int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
+                      float* rec, uint32_t* tiles_touched, uint32_t* rank_of, void* stream);
 
 /* ---- binning: scan tiles_touched -> offsets, emit (tile, rank) instances, sort them by tile
  * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), cut tile
@@ -127,8 +130,7 @@ int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint
  * gradients on the returned 'positions'/'depths'/'scales' (may be NULL).  Gradients of the
  * five parameters are written (accumulate = 0) or added (accumulate = 1) at Gaussian order. */
 int gsx_preprocess_bwd(const float* positions, const float* scales, const float* rotations,
-                       const float* opacity, const float* features, const float* pose,
-                       const uint32_t* order, const float* rec, const uint32_t* offsets,
+                       const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
                        const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                        const float* d_mean2d, const float* d_depth, const float* d_cov2d,
                        int32_t N, int32_t accumulate,

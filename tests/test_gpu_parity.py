@@ -37,9 +37,11 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
     from gaussian_splatting_amd import render as R
     P = tuple(torch.from_numpy(np.ascontiguousarray(params[k], np.float32)).to(dev) for k in PARAMS)
     pose_t = torch.from_numpy(np.ascontiguousarray(pose, np.float32)).to(dev)
-    mean2d, depth, cov2d, keys = R.project(P[0], P[1], P[2], pose_t)
+    mean2d, depth, cov2d, keys, pre = R.project(P[0], P[1], P[2], P[3], P[4], pose_t)
     order_t = R.depth_order(keys) if order is None else torch.from_numpy(order.astype(np.int32)).to(dev)
-    rec, tt = R.build_records(mean2d, depth, cov2d, P[3], P[4], order_t, H, W)
+    rec, tt, rank_of = R.build_records(pre, order_t, H, W)
+    inv = np.empty(P[0].shape[0], np.uint32); inv[_u32(order_t)] = np.arange(P[0].shape[0], dtype=np.uint32)
+    assert np.array_equal(_u32(rank_of), inv), "rank_of is the inverse permutation of order"
     offsets, tiles, ranks, ranges, chunk_base, D = R.bin_instances(rec, tt, H, W)
     n = P[0].shape[0]
     rgb, alpha, dmap, state, chunk_state, max_chunks = R.composite_forward(rec, ranks, ranges, chunk_base, n, H, W, D, True, True)
@@ -54,7 +56,7 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
     lens = (out["ranges"][:, 1] - out["ranges"][:, 0]).astype(np.int64)
     assert np.array_equal(cb, np.concatenate([[0], np.cumsum((lens + 255) // 256)]).astype(np.uint32)), "chunk table"
     assert int(cb[-1]) <= max_chunks
-    out["_t"] = dict(P=P, pose=pose_t, order=order_t, rec=rec, tt=tt, offsets=offsets, ranks=ranks, ranges=ranges,
+    out["_t"] = dict(P=P, pose=pose_t, order=order_t, rank_of=rank_of, rec=rec, tt=tt, offsets=offsets, ranks=ranks, ranges=ranges,
                      chunk_base=chunk_base, chunk_state=chunk_state, max_chunks=max_chunks, state=state, D=D)
     return out
 
@@ -63,7 +65,7 @@ def gpu_backward(gp, H, W, d_rgb, d_mean2d=None, d_depth=None, d_cov=None):
     from gaussian_splatting_amd import render as R
     t = gp["_t"]; dev = t["rec"].device
     vs = R.ViewState()
-    vs.pose, vs.order, vs.rec, vs.tt, vs.offsets = t["pose"], t["order"], t["rec"], t["tt"], t["offsets"]
+    vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = t["pose"], t["order"], t["rank_of"], t["rec"], t["tt"], t["offsets"]
     vs.ranks, vs.ranges, vs.state, vs.D, vs.H, vs.W = t["ranks"], t["ranges"], t["state"], t["D"], H, W
     vs.chunk_base, vs.chunk_state, vs.max_chunks = t["chunk_base"], t["chunk_state"], t["max_chunks"]
     grads = [torch.empty_like(p) for p in t["P"]]
