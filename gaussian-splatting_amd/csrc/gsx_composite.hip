@@ -189,16 +189,32 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     int x, y; pix_xy(pix >> 6, pix & 63, tile % tw, tile / tw, x, y);
     const bool inside = x < W && y < H;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, m = 1.f; int e = 0;
-    for (uint32_t c = c0; c < c1; c++) {
-        const float Tv = ldexpf(m, e);
-        C0 += Tv * *state_ptr(chunk_state, c, 0, pix);
-        C1 += Tv * *state_ptr(chunk_state, c, 1, pix);
-        C2 += Tv * *state_ptr(chunk_state, c, 2, pix);
-        if (DEPTH) Dm += Tv * *state_ptr(chunk_state, c, 5, pix);
-        m *= *state_ptr(chunk_state, c, 3, pix);
-        e += __float_as_int(*state_ptr(chunk_state, c, 4, pix));
-        renorm(m, e);
-        if (need_bwd) { *state_ptr(chunk_state, c, 6, pix) = m; *state_ptr(chunk_state, c, 7, pix) = __int_as_float(e); }
+    // chunk states are independent loads: fetch kCombineBatch chunks ahead of the dependent scan so that the
+    // longest tile (tens of chunks) is not one memory latency per chunk
+    constexpr int kCombineBatch = 8;
+    for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
+        float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch], l5[kCombineBatch];
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; u++) {
+            const uint32_t c = min(cb + u, c1 - 1);
+            l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
+            l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
+            l4[u] = *state_ptr(chunk_state, c, 4, pix);
+            l5[u] = DEPTH ? *state_ptr(chunk_state, c, 5, pix) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; u++) {
+            const uint32_t c = cb + u;
+            if (c < c1) {
+                const float Tv = ldexpf(m, e);
+                C0 += Tv * l0[u]; C1 += Tv * l1[u]; C2 += Tv * l2[u];
+                if (DEPTH) Dm += Tv * l5[u];
+                m *= l3[u];
+                e += __float_as_int(l4[u]);
+                renorm(m, e);
+                if (need_bwd) { *state_ptr(chunk_state, c, 6, pix) = m; *state_ptr(chunk_state, c, 7, pix) = __int_as_float(e); }
+            }
+        }
     }
     const float A = 1.0f - ldexpf(m, e);
     if (inside) {
@@ -214,11 +230,24 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     }
     if (need_bwd) {
         float B0 = 0.f, B1 = 0.f, B2 = 0.f;
-        for (uint32_t c = c1; c-- > c0; ) {
-            const float l0 = *state_ptr(chunk_state, c, 0, pix), l1 = *state_ptr(chunk_state, c, 1, pix), l2 = *state_ptr(chunk_state, c, 2, pix);
-            const float Tl = ldexpf(*state_ptr(chunk_state, c, 3, pix), __float_as_int(*state_ptr(chunk_state, c, 4, pix)));
-            *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
-            B0 = l0 + Tl * B0; B1 = l1 + Tl * B1; B2 = l2 + Tl * B2;
+        for (uint32_t ce = c1; ce > c0; ce -= min((uint32_t)kCombineBatch, ce - c0)) {
+            float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch];
+#pragma unroll
+            for (int u = 0; u < kCombineBatch; u++) {
+                const uint32_t c = (ce - c0 > (uint32_t)u) ? ce - 1 - u : c0;
+                l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
+                l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
+                l4[u] = *state_ptr(chunk_state, c, 4, pix);
+            }
+#pragma unroll
+            for (int u = 0; u < kCombineBatch; u++) {
+                if (ce - c0 > (uint32_t)u) {
+                    const uint32_t c = ce - 1 - u;
+                    const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
+                    *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
+                    B0 = l0[u] + Tl * B0; B1 = l1[u] + Tl * B1; B2 = l2[u] + Tl * B2;
+                }
+            }
         }
     }
 }

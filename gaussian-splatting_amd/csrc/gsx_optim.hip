@@ -16,8 +16,18 @@ struct AdamArgs {
     float* p[kMaxTensors]; float* g[kMaxTensors]; float* m[kMaxTensors]; float* v[kMaxTensors];
     long long begin[kMaxTensors + 1];      // prefix offsets in the virtual concatenation
     float neg_step_size[kMaxTensors];      // -lr / (1 - beta1^t)
+    long long qbegin[kMaxTensors + 1];     // prefix offsets in units of 4-element groups (per tensor: ceil(n/4))
+    int vec[kMaxTensors];                  // 1: all four pointers of the tensor are 16-byte aligned
     int n_tensors;
 };
+
+__device__ __forceinline__ int find_tensor_q(const AdamArgs& a, long long q)
+{
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxTensors; k++) if (k < a.n_tensors && q >= a.qbegin[k]) t = k;
+    return t;
+}
 
 __device__ __forceinline__ int find_tensor(const AdamArgs& a, long long i)
 {
@@ -27,22 +37,29 @@ __device__ __forceinline__ int find_tensor(const AdamArgs& a, long long i)
     return t;
 }
 
-// partial sums of squares over contiguous slices of the virtual concatenation (fixed slicing -> deterministic)
+// partial sums of squares over contiguous slices of the 4-element groups (fixed slicing -> deterministic)
 __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __restrict__ partials)
 {
     __shared__ double s_w[4];
-    const long long total = a.begin[a.n_tensors];
+    const long long total = a.qbegin[a.n_tensors];
     const long long per = (total + kNormBlocks - 1) / kNormBlocks;
     const long long lo = (long long)blockIdx.x * per, hi = min(lo + per, total);
-    double s = 0.0;
-    for (long long i = lo + threadIdx.x; i < hi; i += kBlock) {
-        const int t = find_tensor(a, i);
-        const float x = a.g[t][i - a.begin[t]];
-        s += (double)x * (double)x;
+    float s = 0.0f;
+    for (long long q = lo + threadIdx.x; q < hi; q += kBlock) {
+        const int t = find_tensor_q(a, q);
+        const long long j = (q - a.qbegin[t]) * 4, n = a.begin[t + 1] - a.begin[t];
+        const float* g = a.g[t] + j;
+        if (a.vec[t] && j + 4 <= n) {
+            const float4 x = *reinterpret_cast<const float4*>(g);
+            s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        } else {
+            for (int k = 0; k < 4 && j + k < n; k++) s += g[k] * g[k];
+        }
     }
+    double sd = (double)s;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    for (int d = 32; d > 0; d >>= 1) sd += __shfl_down(sd, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sd;
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
@@ -64,24 +81,46 @@ __global__ __launch_bounds__(kBlock) void clip_coef_kernel(const double* __restr
     }
 }
 
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, bool clip, float coef, float w1, float w2,
+                                         float beta2, float eps, float bc2_sqrt, float neg_step)
+{
+    if (clip) g = g * coef;
+    m = m + w1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2;                           // exp_avg_sq.mul_(beta2)
+    v = v + (w2 * g) * g;                    //           .addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p + neg_step * (m / denom);          // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+
 __global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const float* __restrict__ coef_ptr, int write_clipped_grad,
                                                       float beta1, float beta2, float eps, float bc2_sqrt)
 {
-    const long long total = a.begin[a.n_tensors];
-    const float coef = coef_ptr ? coef_ptr[1] : 1.0f;
+    const long long total = a.qbegin[a.n_tensors];
+    const bool clip = coef_ptr != nullptr;
+    const float coef = clip ? coef_ptr[1] : 1.0f;
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int t = find_tensor(a, i);
-        const long long j = i - a.begin[t];
-        float g = a.g[t][j];
-        if (coef_ptr) { g = g * coef; if (write_clipped_grad) a.g[t][j] = g; }
-        float m = a.m[t][j], v = a.v[t][j];
-        m = m + w1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * beta2;                           // exp_avg_sq.mul_(beta2)
-        v = v + (w2 * g) * g;                    //           .addcmul_(grad, grad, value = 1 - beta2)
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        a.m[t][j] = m; a.v[t][j] = v;
-        a.p[t][j] = a.p[t][j] + a.neg_step_size[t] * (m / denom);   // param.addcdiv_(exp_avg, denom, value = -step_size)
+    for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < total; q += (long long)gridDim.x * kBlock) {
+        const int t = find_tensor_q(a, q);
+        const long long j = (q - a.qbegin[t]) * 4, n = a.begin[t + 1] - a.begin[t];
+        const float ns = a.neg_step_size[t];
+        if (a.vec[t] && j + 4 <= n) {
+            float4 p = *reinterpret_cast<float4*>(a.p[t] + j), g = *reinterpret_cast<float4*>(a.g[t] + j);
+            float4 m = *reinterpret_cast<float4*>(a.m[t] + j), v = *reinterpret_cast<float4*>(a.v[t] + j);
+            adam_one(p.x, g.x, m.x, v.x, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
+            adam_one(p.y, g.y, m.y, v.y, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
+            adam_one(p.z, g.z, m.z, v.z, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
+            adam_one(p.w, g.w, m.w, v.w, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
+            *reinterpret_cast<float4*>(a.p[t] + j) = p; *reinterpret_cast<float4*>(a.m[t] + j) = m;
+            *reinterpret_cast<float4*>(a.v[t] + j) = v;
+            if (clip && write_clipped_grad) *reinterpret_cast<float4*>(a.g[t] + j) = g;
+        } else {
+            for (int k = 0; k < 4 && j + k < n; k++) {
+                float p = a.p[t][j + k], g = a.g[t][j + k], m = a.m[t][j + k], v = a.v[t][j + k];
+                adam_one(p, g, m, v, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
+                a.p[t][j + k] = p; a.m[t][j + k] = m; a.v[t][j + k] = v;
+                if (clip && write_clipped_grad) a.g[t][j + k] = g;
+            }
+        }
     }
 }
 
@@ -109,6 +148,9 @@ GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, flo
         a.p[t] = on ? params_host[t] : nullptr; a.g[t] = on ? grads_host[t] : nullptr;
         a.m[t] = on ? exp_avg_host[t] : nullptr; a.v[t] = on ? exp_avg_sq_host[t] : nullptr;
         a.begin[t + 1] = a.begin[t] + (on ? numel_host[t] : 0);
+        if (t == 0) a.qbegin[0] = 0;
+        a.qbegin[t + 1] = a.qbegin[t] + (on ? (numel_host[t] + 3) / 4 : 0);
+        a.vec[t] = on && ((((uintptr_t)a.p[t] | (uintptr_t)a.g[t] | (uintptr_t)a.m[t] | (uintptr_t)a.v[t]) & 15u) == 0);
         a.neg_step_size[t] = on ? (float)(-(double)lr_host[t] / bc1) : 0.0f;
     }
     const long long total = a.begin[n_tensors];
@@ -121,7 +163,7 @@ GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, flo
         sumsq_kernel<<<dim3(kNormBlocks), dim3(kBlock), 0, st>>>(a, partials);
         clip_coef_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(partials, max_grad_norm, coef);
     }
-    const long long blocks = ceil_div(total, kBlock);
+    const long long blocks = ceil_div(a.qbegin[n_tensors], kBlock);
     adam_kernel<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, st>>>(
         a, coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
     GSX_LAUNCH_CHECK();

@@ -102,8 +102,46 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
     for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
 }
 
+// one workgroup of 1024 threads scans up to kSmallScan values in a single launch (radix histograms of
+// <= 4M keys, the chunk table): a dependent launch costs ~4.6 us, three of them more than the work
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallScan = 8192;         // one sweep
+__global__ __launch_bounds__(kSmallThreads) void scan_small_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                   int64_t n, uint64_t* __restrict__ total)
+{
+    __shared__ uint32_t s_w[kSmallThreads / 64];
+    __shared__ uint64_t s_carry;                              // 64-bit so that *total is exact (prefixes wrap to u32)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    constexpr int kPer = 8;                                   // values per thread per sweep (blocked: 32 B per lane)
+    for (int64_t base = 0; base < n; base += (int64_t)kSmallThreads * kPer) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * kPer;
+        uint32_t v[kPer]; uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { v[k] = (i0 + k < n) ? in[i0 + k] : 0u; s += v[k]; }
+        const uint32_t incl = wave_incl_scan_u32(s);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint64_t wbase = s_carry;
+        for (int w = 0; w < wave; w++) wbase += s_w[w];
+        uint32_t ex = (uint32_t)wbase + incl - s;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { if (i0 + k < n) out[i0 + k] = ex; ex += v[k]; }
+        __syncthreads();
+        if (threadIdx.x == kSmallThreads - 1) s_carry = wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
 static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st)
 {
+    if (n <= kSmallScan) {
+        scan_small_kernel<<<dim3(1), dim3(kSmallThreads), 0, st>>>(in, out, n, total_dev);
+        GSX_LAUNCH_CHECK();
+        return GSX_OK;
+    }
     int64_t nb = ceil_div(n, kScanTile);
     if (ws_bytes < (size_t)nb * 8) return GSX_E_CAPACITY;
     uint64_t* sums = (uint64_t*)ws;
@@ -139,16 +177,39 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
     hist[(size_t)threadIdx.x * nb + blockIdx.x] = s_hist[threadIdx.x];
 }
 
+// one workgroup per digit: exclusive scan of that digit's per-workgroup counts in place, row total -> totals[d].
+// (hist + rowscan + scatter = 3 launches per pass; the scatter kernel turns the 256 totals into digit bases itself)
+__global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nb, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nb;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nb) ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(v, s_wave, &tot);
+        if (i < nb) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                int64_t n, int shift, uint32_t mask,
-                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nb)
+                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nb,
+                                                               const uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t s_run[kRadix];        // next free global slot per digit for this workgroup
     __shared__ uint32_t s_cnt[4][kRadix];     // per-wave counts of the round -> per-wave base slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    s_run[tid] = hist_scanned[(size_t)tid * nb + blockIdx.x];
+    {
+        uint32_t tot;
+        const uint32_t digit_base = block_excl_scan_u32(totals[tid], &s_cnt[0][0], &tot);   // s_cnt reused as scratch
+        s_run[tid] = digit_base + hist_scanned[(size_t)tid * nb + blockIdx.x];
+    }
 
     uint32_t key[kSortItems], val[kSortItems];
 #pragma unroll
@@ -196,7 +257,7 @@ static size_t sort_ws_bytes(int64_t n)
 {
     int64_t nb = ceil_div(n > 0 ? n : 1, kSortTile);
     int64_t hist_n = nb * kRadix;
-    return align_up((size_t)hist_n * 4) + align_up((size_t)ceil_div(hist_n, kScanTile) * 8);
+    return align_up((size_t)hist_n * 4) + align_up((size_t)kRadix * 4);
 }
 
 // Sorts n pairs on key bits [begin_bit, end_bit).  Pass 0 reads (k_in, v_in); passes alternate
@@ -214,8 +275,7 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
     const uint32_t nb = (uint32_t)ceil_div(n, kSortTile);
     const int64_t hist_n = (int64_t)nb * kRadix;
     uint32_t* hist = (uint32_t*)ws;
-    void* scan_ws = (char*)ws + align_up((size_t)hist_n * 4);
-    size_t scan_ws_bytes = ws_bytes - align_up((size_t)hist_n * 4);
+    uint32_t* totals = (uint32_t*)((char*)ws + align_up((size_t)hist_n * 4));
     if (passes == 0) {   // nothing to sort on: copy through
         GSX_HIP(hipMemcpyAsync(k_a, k_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         if (v_in) GSX_HIP(hipMemcpyAsync(v_a, v_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -229,9 +289,8 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
         const int bits = (end_bit - shift) < kRadixBits ? (end_bit - shift) : kRadixBits;
         const uint32_t mask = (1u << bits) - 1u;
         radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, shift, mask, hist, nb);
-        int s = scan_launch(hist, hist, nullptr, hist_n, scan_ws, scan_ws_bytes, st);
-        if (s != GSX_OK) return s;
-        radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, shift, mask, hist, nb);
+        radix_rowscan_kernel<<<dim3(kRadix), dim3(kBlock), 0, st>>>(hist, nb, totals);
+        radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, shift, mask, hist, nb, totals);
         GSX_LAUNCH_CHECK();
         ks = kd; vs = vd;
     }

@@ -240,10 +240,10 @@ class RenderFunction(torch.autograd.Function):
                 order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
             outs.append(o); views.append(vs)
         ctx.params, ctx.views, ctx.hw = params, views, (H, W)
-        rgb = torch.stack([o[0] for o in outs]); alpha = torch.stack([o[1] for o in outs])
-        dmap = torch.stack([o[2] for o in outs]); mean2d = torch.stack([o[3] for o in outs])
-        depth = torch.stack([o[4] for o in outs]); cov2d = torch.stack([o[5] for o in outs])
-        state = torch.stack([vs.state[0] for vs in views])
+        # B == 1 (the reference's only working batch size): views, no copies
+        cat = (lambda i: outs[0][i].unsqueeze(0)) if B == 1 else (lambda i: torch.stack([o[i] for o in outs]))
+        rgb, alpha, dmap, mean2d, depth, cov2d = (cat(i) for i in range(6))
+        state = views[0].state[0:1] if B == 1 else torch.stack([vs.state[0] for vs in views])
         ctx.mark_non_differentiable(alpha, dmap, state)
         return rgb, mean2d, depth, cov2d, alpha, dmap, state
 
