@@ -55,19 +55,65 @@ __device__ __forceinline__ void renorm(float& m, int& e)
     m = __builtin_amdgcn_frexp_mantf(m);
 }
 
-// 4-bit mask of the tile's 8x8 quadrants (bit k: x half k&1, y half k>>1) the splat's pixel box touches.
-// Computed once per record by the staging lane and kept in the LDS copy of the record, so the
-// per-splat loop spends one v_readfirstlane + four scalar bit tests instead of ~40 scalar compares
-// (the CU's single scalar ALU was the bottleneck of the first chunked version).
-__device__ __forceinline__ uint32_t quad_mask(float box_x, float box_y, int qx, int qy)
+// 4-bit mask of the tile's 8x8 quadrants (bit k: x half k&1, y half k>>1) in which the splat can reach
+// |alpha| >= 2^-GSX_CUT_LOG2.  Computed once per record by the staging lane and kept in the LDS copy of
+// the record, so the per-splat loop spends one v_readfirstlane + four scalar bit tests (the CU's single
+// scalar ALU was the bottleneck when the box was compared per quadrant inside the loop).
+// Two tests: the pixel box (exact integers), then -- for a proper (negative definite) conic -- the
+// maximum of the exponent q' over the quadrant's rectangle of pixel centres, which is 0 if the centre
+// lies inside and otherwise sits on one of the four edges (concave quadratic): the quadrant is dropped
+// when o * 2^q'max < 2^-24 with a safety margin.  16% fewer pair evaluations on the orbit views.
+struct QuadEdges { float x[4], y[4]; };   // pixel-centre coordinates of columns/rows 0, 7, 8, 15 of the tile (clamped)
+
+__device__ __forceinline__ float edge_max(float kaa, float kab, float kbb, float fixed, float lo, float hi)
+{
+    // max over t in [lo, hi] of kaa t^2 + kab fixed t + kbb fixed^2, kaa < 0
+    float t = -0.5f * kab * fixed / kaa;
+    t = fminf(fmaxf(t, lo), hi);
+    return kaa * t * t + kab * fixed * t + kbb * fixed * fixed;
+}
+
+__device__ __forceinline__ uint32_t quad_mask(const float4& a, const float4& b, float box_x, float box_y, int qx, int qy,
+                                              const QuadEdges& E)
 {
     const uint32_t bx = __float_as_uint(box_x), by = __float_as_uint(box_y);
     const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
     const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
     const uint32_t mx = (uint32_t)(xlo <= 7 && xhi >= 0) | ((uint32_t)(xlo <= 15 && xhi >= 8) << 1);
     const uint32_t my = (uint32_t)(ylo <= 7 && yhi >= 0) | ((uint32_t)(ylo <= 15 && yhi >= 8) << 1);
-    // bit k = mx[k&1] & my[k>>1]
-    return ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);
+    uint32_t mask = ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);     // bit k = mx[k&1] & my[k>>1]
+    const float k00 = a.z, kb = a.w, k11 = b.x;
+    const bool proper = (k00 < 0.0f) && (k11 < 0.0f) && (4.0f * k00 * k11 - kb * kb > 0.0f);
+    if (proper) {
+        const int e = (int)((__float_as_uint(b.y) >> 23) & 0xff) - 127;           // |o| < 2^(e+1)
+        const float thr = -(float)(GSX_CUT_LOG2 + 1 + e) - 0.0625f;               // margin for rounding
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float ulo = E.x[(k & 1) * 2] - a.x, uhi = E.x[(k & 1) * 2 + 1] - a.x;
+            const float vlo = E.y[(k >> 1) * 2] - a.y, vhi = E.y[(k >> 1) * 2 + 1] - a.y;
+            float qmax = 0.0f;
+            if (!(ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f)) {
+                qmax = fmaxf(fmaxf(edge_max(k00, kb, k11, vlo, ulo, uhi), edge_max(k00, kb, k11, vhi, ulo, uhi)),
+                             fmaxf(edge_max(k11, kb, k00, ulo, vlo, vhi), edge_max(k11, kb, k00, uhi, vlo, vhi)));
+            }
+            if (qmax < thr) mask &= ~(1u << k);
+        }
+    }
+    return mask;
+}
+
+__device__ __forceinline__ QuadEdges quad_edges(int qx, int qy, int H, int W, float stepx, float stepy);
+
+__device__ __forceinline__ QuadEdges quad_edges(int qx, int qy, int H, int W, float stepx, float stepy)
+{
+    QuadEdges E;
+    const int off[4] = {0, 7, 8, 15};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        E.x[i] = pix_coord(min(qx + off[i], W - 1), W, stepx);
+        E.y[i] = pix_coord(min(qy + off[i], H - 1), H, stepy);
+    }
+    return E;
 }
 
 struct ChunkGeom { int tile, tx, ty; uint32_t begin, end; };
@@ -119,6 +165,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
     gy[0] = pix_coord(min(y0, H - 1), H, stepy); gy[1] = pix_coord(min(y0 + 8, H - 1), H, stepy);
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
+    const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     float C0[4], C1[4], C2[4], Dm[4], m[4]; int e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
@@ -129,9 +176,10 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             const uint32_t r = ranks[i];
             s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
+            const float4 a = R[0], b = R[1];
             float4 c = R[2];
-            c.z = __uint_as_float(quad_mask(c.z, c.w, qx, qy));
-            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
+            c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
+            s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)kCBatch, g.end - bs);
@@ -374,6 +422,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
     gy[0] = pix_coord(min(y0, H - 1), H, stepy); gy[1] = pix_coord(min(y0 + 8, H - 1), H, stepy);
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
+    const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     const size_t P = (size_t)H * W;
     float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
 #pragma unroll
@@ -398,8 +447,9 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             const int tx0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, tx1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;
             const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
-            c.z = __uint_as_float(quad_mask(c.z, c.w, qx, qy));
-            s_a[lane] = R[0]; s_b[lane] = R[1]; s_c[lane] = c;
+            const float4 a = R[0], b = R[1];
+            c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
+            s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
         __syncthreads();
         for (uint32_t j = cnt; j-- > 0; ) {
