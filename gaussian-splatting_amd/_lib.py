@@ -16,6 +16,7 @@ SYMBOLS = [
     "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_max_chunks",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
+    "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd",
 ]
 
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
@@ -65,6 +66,9 @@ def lib():
     L.gsx_clip_adam_workspace_bytes.restype = _sz
     L.gsx_clip_adam_step.argtypes = [_i32, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64, C.c_float,
                                      _i32, _p, _sz, _p]
+    L.gsx_image_loss_workspace_bytes.restype = _sz
+    L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
+    L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]
     for name in SYMBOLS:
         getattr(L, name)
         if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name != "gsx_max_chunks":

@@ -116,6 +116,17 @@ __device__ __forceinline__ QuadEdges quad_edges(int qx, int qy, int H, int W, fl
     return E;
 }
 
+// Workgroup -> chunk.  Consecutive chunks belong to the same tile and cost about the same (a dense tile's
+// chunks all run 256 splats x 4 quadrants, a sparse tile's a tenth of that); the dispatcher fills a CU
+// with consecutive workgroups, so the identity map left a few CUs with only heavy waves (measured: VALU
+// 23% busy chip-wide, kernel time = the heaviest SIMD).  A stride walk (multiplication by a prime,
+// bijective mod the chunk count) gives every CU a mix.
+__device__ __forceinline__ uint32_t chunk_of_block(uint32_t block, uint32_t total)
+{
+    const uint32_t stride = (total % 7919u) ? 7919u : 7927u;
+    return (uint32_t)(((uint64_t)block * stride) % total);
+}
+
 struct ChunkGeom { int tile, tx, ty; uint32_t begin, end; };
 
 // chunk -> (tile, instance range).  chunk_base has n_tiles+1 entries (exclusive scan of chunks per tile).
@@ -154,8 +165,9 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_rank[kCBatch];
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= chunk_base[n_tiles]) return;
+    const uint32_t n_chunks = chunk_base[n_tiles];
+    if (blockIdx.x >= n_chunks) return;
+    const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
     uint32_t limit = N;
     if (PASS1) { limit = rank_limit_from_state(state, N); if (limit >= N) return; }
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, m = 1.f; int e = 0;
     // chunk states are independent loads: fetch kCombineBatch chunks ahead of the dependent scan so that the
     // longest tile (tens of chunks) is not one memory latency per chunk
-    constexpr int kCombineBatch = 8;
+    constexpr int kCombineBatch = 16;
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch], l5[kCombineBatch];
 #pragma unroll
@@ -404,8 +416,10 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
     __shared__ float s_out[kCBatch][9];              // raw sums: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy, w*G0..2
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= chunk_base[n_tiles]) return;
+    __shared__ float s_dump[kCBatch * 9 + 64];       // where the lanes that hold no sum store (one bank each)
+    const uint32_t n_chunks = chunk_base[n_tiles];
+    if (blockIdx.x >= n_chunks) return;
+    const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
     const uint32_t limit = rank_limit_from_state(state, N);
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
     // instances of this chunk that were composited: ranks ascend, keep those below the exit rank
@@ -424,6 +438,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
     const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     const size_t P = (size_t)H * W;
+    float* const out_lane = (lane == 63) ? &s_out[0][8] : ((lane & 7) == 0) ? &s_out[0][lane >> 3] : &s_dump[lane];
     float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -481,8 +496,9 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             }
             const float z = wave_reduce8(s0, s1, s2, s3, s4, s5, s6, s7, (lane & 8) != 0);
             s8 = wave_sum_lane63(s8);
-            if ((lane & 7) == 0) s_out[j][lane >> 3] = z;
-            if (lane == 63) s_out[j][8] = s8;
+            // one unpredicated LDS store per splat: lanes 0,8,..,56 hold sums 0..7, lane 63 the ninth, every
+            // other lane writes into a dump row (two exec-masked stores cost 4x as much as this)
+            out_lane[j * 9] = (lane == 63) ? s8 : z;
         }
         __syncthreads();
         // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
@@ -575,4 +591,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 3; }
+GSX_API int gsx_abi_version(void) { return 4; }

@@ -34,15 +34,26 @@ def make_optimizer(model, lrs=None, fused_clip_norm=None):
 
 
 def l1_loss(outputs, target):
-    return (outputs['rendered_images'] - target).abs().mean()
+    """mean |C - target|: one fused HIP pass each way on the GPU (loss.py of this package); plain torch for CPU tensors
+    (host-logic tests only -- the render path itself has no CPU form)."""
+    c = outputs['rendered_images']
+    if c.is_cuda:
+        from . import loss as _loss
+        return _loss.l1(c, target)
+    return (c - target).abs().mean()
 
 
 def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
     """The importable-math subset of model/loss.py:89-109: clamped MSE + scale and opacity
     regularisers (exercises all three gradient routes into the render backward)."""
-    c = outputs['rendered_images'].clamp(1e-8, 1 - 1e-8)
+    c = outputs['rendered_images']
     o = outputs['opacity']
-    return ((c - target) ** 2).mean() + w_scale * torch.norm(outputs['scales'], dim=-1).mean() \
+    if c.is_cuda:
+        from . import loss as _loss
+        rgb = _loss.clamped_mse(c, target)
+    else:
+        rgb = ((c.clamp(1e-8, 1 - 1e-8) - target) ** 2).mean()
+    return rgb + w_scale * torch.norm(outputs['scales'], dim=-1).mean() \
         + w_opacity * (o * (1 - o)).mean()
 
 

@@ -152,6 +152,19 @@ int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, float* cons
                        float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
                        int32_t write_clipped_grad, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the image loss between the render forward and backward of a trainer step (training/trainer.py:144-149;
+ * RGB term = clamped MSE, model/loss.py:126-137).  kind: GSX_LOSS_L1 = mean |pred - target|;
+ * GSX_LOSS_CLAMPED_MSE = mean (clamp(pred, 1e-8, 1 - 1e-8) - target)^2.  n = element count.
+ * fwd writes the scalar loss to *loss (device); ws (device): gsx_image_loss_workspace_bytes().
+ * bwd writes d_pred = dLoss/dpred * upstream[0] (upstream: device scalar, NULL means 1). */
+#define GSX_LOSS_L1 0
+#define GSX_LOSS_CLAMPED_MSE 1
+size_t gsx_image_loss_workspace_bytes(void);
+int gsx_image_loss_fwd(int32_t kind, const float* pred, const float* target, int64_t n,
+                       float* loss, void* ws, size_t ws_bytes, void* stream);
+int gsx_image_loss_bwd(int32_t kind, const float* pred, const float* target, int64_t n,
+                       const float* upstream, float* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

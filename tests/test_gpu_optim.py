@@ -56,3 +56,37 @@ def test_fused_optimizer_rejects_cpu():
     p = torch.nn.Parameter(torch.zeros(4)); p.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         FusedClipAdam([p]).step()
+
+
+@pytest.mark.parametrize("shape,offset", [((1, 3, 37, 53), 0), ((1, 3, 64, 64), 0), ((3, 31, 17), 1)])
+@pytest.mark.parametrize("kind", ["l1", "clamped_mse"])
+def test_fused_image_loss_matches_torch(kind, shape, offset):
+    """gsx_image_loss_fwd/bwd against the torch ops they replace ((x - t).abs().mean(); mse_loss(clamp(x, 1e-8, 1 - 1e-8), t),
+    /root/reference/model/loss.py:135-137).  Tolerance: loss 1e-6 relative (summation order), gradient 1e-6 relative;
+    the L1 gradient (sign/n) is exact."""
+    from gaussian_splatting_amd import loss as gl
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = int(np.prod(shape))
+    base = torch.randn(n + offset, generator=g) * 0.7 + 0.4        # values on both sides of the clamp range
+    tbase = torch.rand(n + offset, generator=g)
+    base[5:9] = tbase[5:9]                                         # exact ties: sign(0) = 0
+    x = base.to(dev)[offset:].view(shape)                          # offset 1 -> pointer not 16-byte aligned
+    t = tbase.to(dev)[offset:].view(shape)
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    if kind == "l1":
+        la = (xa - t).abs().mean(); lb = gl.l1(xb, t)
+    else:
+        la = torch.nn.functional.mse_loss(xa.clamp(1e-8, 1 - 1e-8), t); lb = gl.clamped_mse(xb, t)
+    (la * 3.0).backward(); (lb * 3.0).backward()
+    assert abs(float(la.detach()) - float(lb.detach())) <= 1e-6 * abs(float(la.detach()))
+    if kind == "l1":
+        assert torch.equal(xa.grad, xb.grad)
+    else:
+        assert (xa.grad - xb.grad).abs().max().item() <= 1e-6 * xa.grad.abs().max().item()
+
+
+def test_fused_image_loss_rejects_cpu():
+    from gaussian_splatting_amd import loss as gl
+    with pytest.raises(RuntimeError):
+        gl.l1(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))

@@ -13,6 +13,7 @@ from helpers import (golden_names, load_golden, rel_err, rgb_err, RGB_TOL, GRAD_
                      synth_scene, default_scene, pose_tz, orbit_pose)
 
 pytestmark = pytest.mark.gpu
+from gaussian_splatting_amd._lib import CHUNK as L_CHUNK
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +55,7 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
                n_composited=(s + 1 if (s != 0xFFFFFFFF and s + 1 < n) else n))
     cb = _u32(chunk_base)
     lens = (out["ranges"][:, 1] - out["ranges"][:, 0]).astype(np.int64)
-    assert np.array_equal(cb, np.concatenate([[0], np.cumsum((lens + 255) // 256)]).astype(np.uint32)), "chunk table"
+    assert np.array_equal(cb, np.concatenate([[0], np.cumsum((lens + L_CHUNK - 1) // L_CHUNK)]).astype(np.uint32)), "chunk table"
     assert int(cb[-1]) <= max_chunks
     out["_t"] = dict(P=P, pose=pose_t, order=order_t, rank_of=rank_of, rec=rec, tt=tt, offsets=offsets, ranks=ranks, ranges=ranges,
                      chunk_base=chunk_base, chunk_state=chunk_state, max_chunks=max_chunks, state=state, D=D)
