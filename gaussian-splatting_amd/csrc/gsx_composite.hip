@@ -376,35 +376,53 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
     return v;
 }
 
-// Reduce EIGHT per-lane values over the wave at once (reduce-scatter): v_permlane32_swap /
-// v_permlane16_swap halve the register count at distances 32 and 16, a DPP rotate + select at
-// distance 8, then three DPP adds inside each 8-lane group: 18 VALU instead of 48.
-// On return lane l holds the wave total of value (l >> 3).  Fixed order -> deterministic.
-// (inline asm: ROCm 7.2's __builtin_amdgcn_permlane{32,16}_swap returns the FIRST register for both
-// results; the s_nop 1 on each side are the VALU wait states hipcc would have placed around it)
-__device__ __forceinline__ float swap_add32(float a, float b)
+// Reduce the NINE per-lane sums of one splat over the wave in one hand-scheduled block.
+//   a0..a7: reduce-scatter -- v_permlane32_swap / v_permlane16_swap halve the register count at distances 32
+//           and 16, a DPP rotate + select at distance 8, three DPP adds inside each 8-lane group; lane l ends
+//           up with the wave total of value (l >> 3).
+//   b     : plain DPP reduction (4 row steps, row_bcast:15, row_bcast:31), total valid in lane 63.
+// Returned: lane 63 -> total of b, every other lane l -> total of a[l >> 3].  Fixed order -> deterministic.
+// Why asm: (1) ROCm 7.2's __builtin_amdgcn_permlane{32,16}_swap returns the FIRST register for both results;
+// (2) a DPP or permlane-swap read needs 2 wait states after the VALU write of its source, and an s_nop costs
+// a full 4-cycle issue slot on gfx950 -- written as separate statements this reduction carried 18 of them
+// (a third of its issue time).  Here the two dependency chains are interleaved so that 4 remain.
+// Slot numbers in the comments: producer -> consumer distances are all >= 3 (2 instructions between).
+__device__ __forceinline__ float wave_reduce9(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
+                                              float b, unsigned long long hi8_mask, unsigned long long lane63_mask)
 {
-    // lanes 32..63 of a <-> lanes 0..31 of b
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-__device__ __forceinline__ float swap_add16(float a, float b)
-{
-    // 16-lane rows 1,3 of a <-> rows 0,2 of b
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-__device__ __forceinline__ float wave_reduce8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, bool hi8)
-{
-    const float u0 = swap_add32(v0, v4), u1 = swap_add32(v1, v5), u2 = swap_add32(v2, v6), u3 = swap_add32(v3, v7);
-    const float w0 = swap_add16(u0, u2), w1 = swap_add16(u1, u3);
-    const float t0 = w0 + dpp_mov<0x128>(w0);        // row_ror:8
-    const float t1 = w1 + dpp_mov<0x128>(w1);
-    float z = hi8 ? t1 : t0;
-    z += dpp_mov<0x141>(z);                           // row_half_mirror: lane i <-> 7-i inside each 8
-    z += dpp_mov<0xB1>(z);                            // quad_perm [1,0,3,2]
-    z += dpp_mov<0x4E>(z);                            // quad_perm [2,3,0,1]
-    return z;
+    asm volatile(
+        "s_nop 1\n\t"                                                                     //  0 inputs may be fresh
+        "v_permlane32_swap_b32 %0, %4\n\t"                                                //  1
+        "v_permlane32_swap_b32 %2, %6\n\t"                                                //  2
+        "v_permlane32_swap_b32 %1, %5\n\t"                                                //  3
+        "v_permlane32_swap_b32 %3, %7\n\t"                                                //  4
+        "v_add_f32 %0, %0, %4\n\t"                                                        //  5 u0 (1)
+        "v_add_f32 %2, %2, %6\n\t"                                                        //  6 u2 (2)
+        "v_add_f32 %1, %1, %5\n\t"                                                        //  7 u1 (3)
+        "v_add_f32 %3, %3, %7\n\t"                                                        //  8 u3 (4)
+        "v_permlane16_swap_b32 %0, %2\n\t"                                                //  9 (5, 6)
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // 10 b
+        "v_permlane16_swap_b32 %1, %3\n\t"                                                // 11 (7, 8)
+        "v_add_f32 %0, %0, %2\n\t"                                                        // 12 w0 (9)
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // 13 b (10)
+        "v_add_f32 %1, %1, %3\n\t"                                                        // 14 w1 (11)
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"               // 15 (12)
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         // 16 b (13)
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"               // 17 (14)
+        "v_cndmask_b32_e64 %0, %0, %1, %9\n\t"                                            // 18 z = lane&8 ? w1' : w0'
+        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"              // 19 b (16)
+        "s_nop 0\n\t"                                                                     // 20
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         // 21 z (18)
+        "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"            // 22 b (19): rows 1,3 += row 0,2 totals
+        "s_nop 0\n\t"                                                                     // 23
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // 24 z (21)
+        "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"            // 25 b (22): rows 2,3 += lane 31
+        "s_nop 0\n\t"                                                                     // 26
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // 27 z (24)
+        "v_cndmask_b32_e64 %0, %0, %8, %10"                                                 // 28 lane 63 takes b
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b)
+        : "s"(hi8_mask), "s"(lane63_mask));
+    return a0;
 }
 
 __global__ __launch_bounds__(64) void chunk_bwd_kernel(
@@ -415,8 +433,9 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
-    __shared__ float s_out[kCBatch][9];              // raw sums: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy, w*G0..2
-    __shared__ float s_dump[kCBatch * 9 + 64];       // where the lanes that hold no sum store (one bank each)
+    // raw sums per staged splat: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy (dq = dL/dalpha * alpha), w*G0..2;
+    // the second half is a dump area for the lanes that hold no sum (one bank each)
+    __shared__ float s_red[2 * kCBatch * 9 + 64];
     const uint32_t n_chunks = chunk_base[n_tiles];
     if (blockIdx.x >= n_chunks) return;
     const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
@@ -438,7 +457,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
     const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     const size_t P = (size_t)H * W;
-    float* const out_lane = (lane == 63) ? &s_out[0][8] : ((lane & 7) == 0) ? &s_out[0][lane >> 3] : &s_dump[lane];
+    const int out_lane = (lane == 63) ? 8 : ((lane & 7) == 0) ? (lane >> 3) : kCBatch * 9 + lane;
+    const unsigned long long hi8_mask = 0xFF00FF00FF00FF00ull, lane63_mask = 0x8000000000000000ull;
     float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -483,7 +503,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
                     const float cG = b.z * G0[k] + b.w * G1[k] + c.x * G2[k];
                     const float dal = Tv * (cG - Wb[k]);              // dL/dalpha_k
                     Wb[k] = al * cG + f * Wb[k];
-                    const float dq = dal * al * GSX_LN2;              // dL/dq'  (alpha = o * exp2(q'))
+                    const float dq = dal * al;                        // dL/dq' / ln2  (alpha = o * exp2(q'))
                     const float wv = Tv * al;
                     s0 += dq; s1 += dq * dx; s2 += dq * dy;
                     s3 += dq * dx * dx; s4 += dq * dx * dy; s5 += dq * dy * dy;
@@ -494,22 +514,20 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
-            const float z = wave_reduce8(s0, s1, s2, s3, s4, s5, s6, s7, (lane & 8) != 0);
-            s8 = wave_sum_lane63(s8);
             // one unpredicated LDS store per splat: lanes 0,8,..,56 hold sums 0..7, lane 63 the ninth, every
-            // other lane writes into a dump row (two exec-masked stores cost 4x as much as this)
-            out_lane[j * 9] = (lane == 63) ? s8 : z;
+            // other lane writes into the dump area (two exec-masked stores cost 4x as much as this)
+            s_red[out_lane + (int)j * 9] = wave_reduce9(s0, s1, s2, s3, s4, s5, s6, s7, s8, hi8_mask, lane63_mask);
         }
         __syncthreads();
         // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
         for (uint32_t idx = lane; idx < cnt * 9u; idx += 64) {
             const uint32_t j = idx / 9u, c = idx - j * 9u;
-            const float* sp = s_out[j];
+            const float* sp = s_red + j * 9u;
             float out;
-            if (c == 0)      out = -(2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
-            else if (c == 1) out = -(s_a[j].w * sp[1] + 2.0f * s_b[j].x * sp[2]);
-            else if (c <= 4) out = sp[c + 1];
-            else if (c == 5) out = sp[0] / (s_b[j].y * GSX_LN2);
+            if (c == 0)      out = -GSX_LN2 * (2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
+            else if (c == 1) out = -GSX_LN2 * (s_a[j].w * sp[1] + 2.0f * s_b[j].x * sp[2]);
+            else if (c <= 4) out = GSX_LN2 * sp[c + 1];
+            else if (c == 5) out = sp[0] / s_b[j].y;
             else             out = sp[c];
             partials[(size_t)s_slot[j] * 9u + c] = out;
         }
