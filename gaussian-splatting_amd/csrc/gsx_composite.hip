@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
     bool stop = false;
+    uint32_t active = 0;
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
         if (i < g.end) {
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             if (PASS1) { if (s_rank[j] >= limit) { stop = true; break; } }
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
             const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
+            if (mk == 0u) continue;                           // inside the tile's box but outside the ellipse
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (mk & (1u << k)) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
                     m[k] *= one_minus(al);
                 }
             }
-            if ((j & 3) == 3) {
+            if ((++active & 3u) == 0u) {                       // every 4 composited splats: |m| stays within 2^+-120
 #pragma unroll
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
@@ -367,15 +369,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
 // ------------------------------------------------------------------------------------------
 // B1: backward, one wave per chunk, back to front
 // ------------------------------------------------------------------------------------------
-// wave64 total of v, valid in lane 63: 16-lane row sums, then row_bcast15 / row_bcast31 (fixed order -> deterministic)
-__device__ __forceinline__ float wave_sum_lane63(float v)
-{
-    v = row_sum16(v);
-    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
-    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 // Reduce the NINE per-lane sums of one splat over the wave in one hand-scheduled block.
 //   a0..a7: reduce-scatter -- v_permlane32_swap / v_permlane16_swap halve the register count at distances 32
 //           and 16, a DPP rotate + select at distance 8, three DPP adds inside each 8-lane group; lane l ends
@@ -471,6 +464,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         m[k] = cs[6 * kPixPerTile]; e[k] = __float_as_int(cs[7 * kPixPerTile]);
     }
     const uint32_t nb = (eff_end - g.begin + kCBatch - 1) / kCBatch;
+    uint32_t active = 0;
     for (uint32_t bi = nb; bi-- > 0; ) {
         const uint32_t bs = g.begin + bi * kCBatch;
         const uint32_t cnt = min((uint32_t)kCBatch, eff_end - bs);
@@ -490,6 +484,10 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         for (uint32_t j = cnt; j-- > 0; ) {
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
             const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
+            if (mk == 0u) {                                   // inside the tile's box but outside the ellipse: a zero row
+                s_red[out_lane + (int)j * 9] = 0.f;
+                continue;
+            }
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
                     s6 += wv * G0[k]; s7 += wv * G1[k]; s8 += wv * G2[k];
                 }
             }
-            if ((j & 3) == 0) {
+            if ((++active & 3u) == 0u) {                       // every 4 composited splats: |m| stays within 2^+-120
 #pragma unroll
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
