@@ -30,6 +30,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+# stage -> kernel whose PMC traffic (profiles/r1_pmc_hbm_traffic.json, separate rocprofv3 --pmc passes) belongs to it
+STAGE_KERNEL = {"composite_bwd": "gsx::chunk_bwd_kernel", "composite_fwd": "gsx::chunk_fwd_kernel<false, true>",
+                "preprocess_bwd": "gsx::preprocess_bwd_kernel", "build_records": "gsx::build_records_kernel",
+                "project_fwd": "gsx::project_fwd_kernel"}
+
+
+def pmc_traffic_bytes(stage):
+    """HBM bytes per launch of the stage's kernel from the committed PMC summary (None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"][STAGE_KERNEL[stage]]
+        return int(k["hbm_total_MB"] * 1024 * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_bytes(stage, n, d, p):
@@ -144,11 +158,15 @@ def main():
         stages = {k: round(t / c, 4) for k, (t, c) in tot.items()}
         dom = max(("composite_fwd", "composite_bwd", "depth_sort", "bin_instances", "project_fwd", "build_records",
                    "preprocess_bwd"), key=lambda k: stages.get(k, 0.0))
-        ach = algorithmic_bytes(dom, n, d_avg, H * W) / (stages[dom] * 1e-3) / 1e9
+        alg = algorithmic_bytes(dom, n, d_avg, H * W)
+        ach = alg / (stages[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_bytes(dom),
+                    "algorithmic_bytes_per_launch": int(alg),
                     "avg_launch_ms": stages[dom], "avg_instances_D": int(d_avg),
-                    "note": "VALU-bound compositing: the HBM fraction is small by construction, see DESIGN.md 4"}
+                    "note": "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                            "(profiles/r1_pmc_hbm_traffic.json; reads x2 as the gfx950 guide prescribes). The kernel is "
+                            "VALU-issue bound (85% of issue slots, DESIGN.md 4): its HBM fraction is small by construction"}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
     const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     const size_t P = (size_t)H * W;
-    const int out_lane = (lane == 63) ? 8 : ((lane & 7) == 0) ? (lane >> 3) : kCBatch * 9 + lane;
+    const uint32_t out_lane = (lane == 63) ? 8u : ((lane & 7) == 0) ? (uint32_t)(lane >> 3) : (uint32_t)(kCBatch * 9 + lane);
     const unsigned long long hi8_mask = 0xFF00FF00FF00FF00ull, lane63_mask = 0x8000000000000000ull;
     float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
 #pragma unroll
@@ -481,11 +481,13 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
         __syncthreads();
+        uint32_t slot = (out_lane + cnt * 9u) * 4u;                // walks down with j (a multiply here compiles to a quarter-rate 64-bit mad)
         for (uint32_t j = cnt; j-- > 0; ) {
+            slot -= 36u;                                      // byte offset into s_red
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
             const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
             if (mk == 0u) {                                   // inside the tile's box but outside the ellipse: a zero row
-                s_red[out_lane + (int)j * 9] = 0.f;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(s_red) + slot) = 0.f;
                 continue;
             }
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             }
             // one unpredicated LDS store per splat: lanes 0,8,..,56 hold sums 0..7, lane 63 the ninth, every
             // other lane writes into the dump area (two exec-masked stores cost 4x as much as this)
-            s_red[out_lane + (int)j * 9] = wave_reduce9(s0, s1, s2, s3, s4, s5, s6, s7, s8, hi8_mask, lane63_mask);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(s_red) + slot) = wave_reduce9(s0, s1, s2, s3, s4, s5, s6, s7, s8, hi8_mask, lane63_mask);
         }
         __syncthreads();
         // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
