@@ -34,6 +34,9 @@ class GaussianSplat(nn.Module):
         self.features = nn.Parameter(torch.randn(num_gaussians, 3))
         self._initialize_parameters()
         self._last_state = None
+        # extra output beyond the reference's six keys: 'depth_map' (alpha-composited camera depth); off by default,
+        # it costs an accumulator per pixel in the compositing kernels
+        self.render_depth_map = False
 
     def _initialize_parameters(self):
         """:46-63"""
@@ -53,16 +56,16 @@ class GaussianSplat(nn.Module):
     def forward(self, camera_poses: torch.Tensor, image_size: Tuple[int, int]) -> Dict[str, torch.Tensor]:
         """camera_poses (B,4,4) applied as world->camera exactly like the reference (:250-253);
         image_size (H, W).  Returns the reference's six keys (:212-219) plus `alpha (B,1,H,W)`
-        (accumulated alpha, which the reference computes but never returns, :97) and
-        `depth_map (B,1,H,W)` (alpha-composited camera depth)."""
+        (accumulated alpha, which the reference computes but never returns, :97) and, with
+        `self.render_depth_map = True`, `depth_map (B,1,H,W)` (alpha-composited camera depth)."""
         if camera_poses.dim() != 3 or camera_poses.shape[-2:] != (4, 4):
             raise ValueError(f"camera_poses must be (B,4,4), got {tuple(camera_poses.shape)}")
         H, W = int(image_size[0]), int(image_size[1])
         rgb, mean2d, depth, cov2d, alpha, dmap, state = render_views(
             self.positions, self.scales, self.rotations, self.opacity, self.features,
-            camera_poses.to(self.positions.device), (H, W))
+            camera_poses.to(self.positions.device), (H, W), want_depth=self.render_depth_map)
         self._last_state = state
-        return {
+        out = {
             'rendered_images': rgb,
             'positions': mean2d,
             'depths': depth,
@@ -70,8 +73,10 @@ class GaussianSplat(nn.Module):
             'features': self.features,
             'opacity': self.opacity,
             'alpha': alpha,
-            'depth_map': dmap,
         }
+        if self.render_depth_map:
+            out['depth_map'] = dmap
+        return out
 
     def last_n_composited(self):
         """Number of Gaussians composited before the global early exit (:147) in the last

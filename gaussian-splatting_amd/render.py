@@ -223,7 +223,7 @@ class RenderFunction(torch.autograd.Function):
        alpha (B,1,H,W), depth_map (B,1,H,W), n_composited-state (B,) [last three non-differentiable]"""
 
     @staticmethod
-    def forward(ctx, positions, scales, rotations, opacity, features, poses, H, W):
+    def forward(ctx, positions, scales, rotations, opacity, features, poses, H, W, want_depth=True):
         if not positions.is_cuda:
             raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
                                "there is no CPU fallback")
@@ -235,14 +235,15 @@ class RenderFunction(torch.autograd.Function):
         outs, views = [], []
         order = None
         for b in range(B):
-            o, vs, _ = forward_view(params, poses[b], H, W, order=order, need_bwd=need_bwd)
+            o, vs, _ = forward_view(params, poses[b], H, W, order=order, want_depth=want_depth, need_bwd=need_bwd)
             if order is None:
                 order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
             outs.append(o); views.append(vs)
         ctx.params, ctx.views, ctx.hw = params, views, (H, W)
         # B == 1 (the reference's only working batch size): views, no copies
         cat = (lambda i: outs[0][i].unsqueeze(0)) if B == 1 else (lambda i: torch.stack([o[i] for o in outs]))
-        rgb, alpha, dmap, mean2d, depth, cov2d = (cat(i) for i in range(6))
+        rgb, alpha, dmap, mean2d, depth, cov2d = (cat(i) if outs[0][i] is not None else rgb_placeholder(outs[0][0])
+                                                  for i in range(6))
         state = views[0].state[0:1] if B == 1 else torch.stack([vs.state[0] for vs in views])
         ctx.mark_non_differentiable(alpha, dmap, state)
         return rgb, mean2d, depth, cov2d, alpha, dmap, state
@@ -264,9 +265,16 @@ class RenderFunction(torch.autograd.Function):
                           None if d_depth is None else _f32c(d_depth[b]),
                           None if d_cov2d is None else _f32c(d_cov2d[b]),
                           grads, accumulate=(b > 0))
-        return grads[0], grads[1], grads[2], grads[3], grads[4], None, None, None
+        return grads[0], grads[1], grads[2], grads[3], grads[4], None, None, None, None
 
 
-def render_views(positions, scales, rotations, opacity, features, poses, image_size):
+def rgb_placeholder(like):
+    """Empty stand-in for an output that was not requested (autograd Functions must return tensors)."""
+    return like.new_empty(0)
+
+
+def render_views(positions, scales, rotations, opacity, features, poses, image_size, want_depth=True):
+    """want_depth=False skips the alpha-composited depth map (the reference has none): one accumulator and one
+    chunk-state word less per pixel in the compositing kernels; the depth_map output is then an empty tensor."""
     H, W = int(image_size[0]), int(image_size[1])
-    return RenderFunction.apply(positions, scales, rotations, opacity, features, poses, H, W)
+    return RenderFunction.apply(positions, scales, rotations, opacity, features, poses, H, W, want_depth)

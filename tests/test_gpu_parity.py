@@ -235,6 +235,12 @@ def test_module_dropin_matches_reference_outputs(dev):
     assert rgb_err(out["rendered_images"][0].detach().cpu().numpy(), fx) < RGB_TOL
     for k in PARAMS:
         assert rel_err(getattr(m, k).grad.cpu().numpy(), fx["g_" + k]) < GRAD_RTOL, k
+    # the depth map is an extra (the reference returns none): off by default, same image with it on
+    assert "depth_map" not in out
+    m.render_depth_map = True
+    out2 = m(torch.from_numpy(fx["poses"]).to(dev), (fx["H"], fx["W"]))
+    assert out2["depth_map"].shape == (1, 1, fx["H"], fx["W"])
+    assert torch.equal(out2["rendered_images"], out["rendered_images"])
 
 
 def test_cpu_tensors_fail_loudly():
