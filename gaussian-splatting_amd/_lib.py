@@ -13,7 +13,7 @@ SYMBOLS = [
     "gsx_strerror", "gsx_last_hip_error", "gsx_abi_version",
     "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32",
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
-    "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_max_chunks",
+    "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd",
@@ -59,6 +59,8 @@ def lib():
     L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p]
     L.gsx_bin_workspace_bytes.restype = _sz; L.gsx_bin_workspace_bytes.argtypes = [_i32, _i64]
     L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
+    L.gsx_bin_count.argtypes = [_p, _i32, _p, _p, _p, _p, _sz, _p]
+    L.gsx_bin_emit_sort.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
     L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]

@@ -6,14 +6,15 @@
 
 namespace gsx {
 
-int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, int, int,
+int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, const uint64_t*, int, int,
                         void*, size_t, hipStream_t);
 int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t);
 size_t sort_ws_bytes_internal(int64_t n);
 
-// one thread per rank: write its tiles row-major at offsets[r]..
+// one thread per rank: write its tiles row-major at offsets[r]..  Writes stop at `capacity` (the caller finds
+// out that the buffers were too small when it reads the instance count, and retries).
 __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ offsets, int N, int tw,
-                                                      uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
+                                                      uint32_t capacity, uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= N) return;
@@ -25,7 +26,10 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ 
     const int y0 = ylo >> GSX_TILE_SHIFT, y1 = (yhi >> GSX_TILE_SHIFT) + 1;
     uint32_t o = offsets[r];
     for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) { tiles[o] = (uint32_t)(ty * tw + tx); ranks[o] = (uint32_t)r; o++; }
+        for (int tx = x0; tx < x1; tx++) {
+            if (o >= capacity) return;
+            tiles[o] = (uint32_t)(ty * tw + tx); ranks[o] = (uint32_t)r; o++;
+        }
 }
 
 // ranges[t] = [lower_bound(tiles, t), lower_bound(tiles, t+1))
@@ -37,9 +41,12 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
 }
 // also counts the tile's compositing chunks (GSX_CHUNK instances each); entry n_tiles is 0 so that
 // the exclusive scan of chunk_cnt[0..n_tiles] ends with the total
-__global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, uint32_t D, int n_tiles,
+__global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, const uint64_t* __restrict__ total_dev,
+                                                        uint32_t capacity, int n_tiles,
                                                         uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_cnt)
 {
+    const uint64_t total = *total_dev;
+    const uint32_t D = total < capacity ? (uint32_t)total : capacity;
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t > n_tiles) return;
     if (t == n_tiles) { chunk_cnt[t] = 0; return; }
@@ -73,6 +80,47 @@ GSX_API int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W)
     return D / GSX_CHUNK + (D < n_tiles ? D : n_tiles);
 }
 
+GSX_API int gsx_bin_count(const uint32_t* tiles_touched, int32_t N, uint32_t* offsets, uint64_t* total_dev,
+                          int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream)
+{
+    if (N < 0 || !total_dev) return GSX_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 0 && (!tiles_touched || !offsets || !ws || ws_bytes < gsx_scan_workspace_bytes(N))) return GSX_E_INVALID;
+    int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st);     // N == 0: total = 0
+    if (s != GSX_OK) return s;
+    if (D_pinned_host) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 8, hipMemcpyDeviceToHost, st));
+    return GSX_OK;
+}
+
+GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                              int64_t capacity, const uint64_t* total_dev,
+                              uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                              uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity <= 0) return GSX_E_INVALID;
+    if (capacity >= 0xFFFFFFFFll) return GSX_E_RANGE;
+    if (!ranges || !chunk_base || !total_dev || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
+    if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
+    if (N > 0 && (!rec || !offsets)) return GSX_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
+    void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
+    const int bits = tile_bits(n_tiles);
+    const int passes = (bits + 7) / 8;
+    // emit into the buffer the sort does NOT write first, so that the last pass lands in *_sorted
+    uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;
+    uint32_t* e_r = (passes & 1) ? ranks_tmp : ranks_sorted;
+    if (N > 0) {
+        emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, (uint32_t)capacity, e_t, e_r);
+        GSX_LAUNCH_CHECK();
+        int s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, capacity, total_dev, 0, bits, sub_ws, sub_bytes, st);
+        if (s != GSX_OK) return s;
+    }
+    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, total_dev, (uint32_t)capacity, n_tiles, ranges, chunk_base);
+    GSX_LAUNCH_CHECK();
+    return scan_internal(chunk_base, chunk_base, nullptr, (int64_t)n_tiles + 1, sub_ws, sub_bytes, st);
+}
+
 GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
                               int64_t capacity, uint32_t* offsets,
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
@@ -92,7 +140,7 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     if (!rec || !tiles_touched || !offsets) return GSX_E_INVALID;
     uint64_t* total_dev = (uint64_t*)ws;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
-    int s = scan_internal(tiles_touched, offsets, total_dev, N, sub_ws, sub_bytes, st);
+    int s = gsx_bin_count(tiles_touched, N, offsets, total_dev, nullptr, sub_ws, sub_bytes, stream);
     if (s != GSX_OK) return s;
     uint64_t D = 0;
     GSX_HIP(hipMemcpyAsync(&D, total_dev, 8, hipMemcpyDeviceToHost, st));
@@ -101,17 +149,6 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     if (D >= 0xFFFFFFFFull) return GSX_E_RANGE;
     if ((int64_t)D > capacity) return GSX_E_CAPACITY;
     if (D == 0) return empty();
-    if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
-    const int bits = tile_bits(n_tiles);
-    const int passes = (bits + 7) / 8;
-    // emit into the buffer the sort does NOT write first, so that the last pass lands in *_sorted
-    uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;
-    uint32_t* e_r = (passes & 1) ? ranks_tmp : ranks_sorted;
-    emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, e_t, e_r);
-    GSX_LAUNCH_CHECK();
-    s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, (int64_t)D, 0, bits, sub_ws, sub_bytes, st);
-    if (s != GSX_OK) return s;
-    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, (uint32_t)D, n_tiles, ranges, chunk_base);
-    GSX_LAUNCH_CHECK();
-    return scan_internal(chunk_base, chunk_base, nullptr, (int64_t)n_tiles + 1, sub_ws, sub_bytes, st);
+    return gsx_bin_emit_sort(rec, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
+                             ranges, chunk_base, ws, ws_bytes, stream);
 }

@@ -157,14 +157,24 @@ static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, i
 // ------------------------------------------------------------------------------------------
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
-constexpr int kSortItems = 16;                      // keys per thread
+constexpr int kSortItems = 8;                       // keys per thread
 constexpr int kSortTile = kBlock * kSortItems;      // 4096 keys per workgroup
 
 // hist[d * nb + b] = number of keys of workgroup b with digit d
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t mask,
-                                                            uint32_t* __restrict__ hist, uint32_t nb)
+// n_dev (nullable): element count in device memory, clamped to n -- lets the binning stage enqueue the sort
+// before the host knows the instance count (the grid is then sized by the buffers' capacity)
+__device__ __forceinline__ int64_t device_count(const uint64_t* __restrict__ n_dev, int64_t n)
+{
+    if (!n_dev) return n;
+    const uint64_t d = *n_dev;
+    return d < (uint64_t)n ? (int64_t)d : n;
+}
+
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ n_dev,
+                                                            int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nb)
 {
     __shared__ uint32_t s_hist[kRadix];
+    n = device_count(n_dev, n);
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -195,36 +205,40 @@ __global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restr
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Stable scatter of one 4096-key tile.  Each wave owns a CONTIGUOUS quarter of the tile (16 rounds of 64
+// consecutive keys), ranks its keys against its own running digit counters in LDS (same-wave LDS operations
+// retire in order, so the rounds need no barrier), and only then do the four waves meet once to turn the
+// counters into global slots: 3 barriers per tile instead of 4 per round.
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                               int64_t n, int shift, uint32_t mask,
+                                                               int64_t n, const uint64_t* __restrict__ n_dev, int shift, uint32_t mask,
                                                                const uint32_t* __restrict__ hist_scanned, uint32_t nb,
                                                                const uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_run[kRadix];        // next free global slot per digit for this workgroup
-    __shared__ uint32_t s_cnt[4][kRadix];     // per-wave counts of the round -> per-wave base slots
+    __shared__ uint32_t s_cnt[4][kRadix];     // per-wave digit counts, then per-wave global base slots
+    n = device_count(n_dev, n);
+    __shared__ uint32_t s_scan[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    {
-        uint32_t tot;
-        const uint32_t digit_base = block_excl_scan_u32(totals[tid], &s_cnt[0][0], &tot);   // s_cnt reused as scratch
-        s_run[tid] = digit_base + hist_scanned[(size_t)tid * nb + blockIdx.x];
-    }
+    constexpr int kWaveKeys = kSortTile / 4;  // 1024
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * kWaveKeys;
+    uint32_t tot;
+    const uint32_t digit_base = block_excl_scan_u32(totals[tid], s_scan, &tot);   // two barriers inside
+    s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
 
-    uint32_t key[kSortItems], val[kSortItems];
+    uint32_t key[kSortItems], val[kSortItems], loc[kSortItems];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
-        int64_t i = base + k * kBlock + tid;
+        const int64_t i = base + k * 64 + lane;
         key[k] = (i < n) ? keys_in[i] : 0xFFFFFFFFu;
         val[k] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
+    __syncthreads();                          // counters zeroed
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* cnt = s_cnt[wave];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
-        const int64_t i = base + k * kBlock + tid;
-        const bool valid = i < n;
+        const bool valid = base + k * 64 + lane < n;
         const uint32_t d = (key[k] >> shift) & mask;
-        s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
         // lanes of this wave holding the same digit (stable: lane order == key order)
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -234,22 +248,24 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
             peers &= bit ? bal : ~bal;
         }
         const uint32_t rank = __popcll(peers & lt_mask);
-        __syncthreads();
-        if (valid && rank == 0) s_cnt[wave][d] = __popcll(peers);
-        __syncthreads();
-        {
-            const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
-            const uint32_t r0 = s_run[tid];
-            s_cnt[0][tid] = r0; s_cnt[1][tid] = r0 + c0; s_cnt[2][tid] = r0 + c0 + c1; s_cnt[3][tid] = r0 + c0 + c1 + c2;
-            s_run[tid] = r0 + c0 + c1 + c2 + c3;
-        }
-        __syncthreads();
-        if (valid) {
-            const uint32_t dst = s_cnt[wave][d] + rank;
+        const uint32_t old = cnt[d];                                   // every lane reads before the leader writes
+        if (valid && rank == 0) cnt[d] = old + __popcll(peers);
+        loc[k] = old + rank;
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid];
+        const uint32_t r0 = digit_base + hist_scanned[(size_t)tid * nb + blockIdx.x];
+        s_cnt[0][tid] = r0; s_cnt[1][tid] = r0 + c0; s_cnt[2][tid] = r0 + c0 + c1; s_cnt[3][tid] = r0 + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        if (base + k * 64 + lane < n) {
+            const uint32_t dst = cnt[(key[k] >> shift) & mask] + loc[k];
             keys_out[dst] = key[k];
             vals_out[dst] = val[k];
         }
-        __syncthreads();
     }
 }
 
@@ -264,8 +280,9 @@ static size_t sort_ws_bytes(int64_t n)
 // between (k_a, v_a) and (k_b, v_b) such that the LAST pass writes (k_a, v_a).  No pass reads and
 // writes the same buffer provided k_in differs from the first destination:
 //   odd pass count  -> first destination is a;  even -> first destination is b.
+// n_dev != NULL: the real count lives in device memory (clamped to n, which then only sizes the grids).
 int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_a, uint32_t* v_a,
-                        uint32_t* k_b, uint32_t* v_b, int64_t n, int begin_bit, int end_bit,
+                        uint32_t* k_b, uint32_t* v_b, int64_t n, const uint64_t* n_dev, int begin_bit, int end_bit,
                         void* ws, size_t ws_bytes, hipStream_t st)
 {
     if (n <= 0) return GSX_OK;
@@ -288,9 +305,9 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
         const int shift = begin_bit + p * kRadixBits;
         const int bits = (end_bit - shift) < kRadixBits ? (end_bit - shift) : kRadixBits;
         const uint32_t mask = (1u << bits) - 1u;
-        radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, shift, mask, hist, nb);
+        radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, n_dev, shift, mask, hist, nb);
         radix_rowscan_kernel<<<dim3(kRadix), dim3(kBlock), 0, st>>>(hist, nb, totals);
-        radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, shift, mask, hist, nb, totals);
+        radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, n_dev, shift, mask, hist, nb, totals);
         GSX_LAUNCH_CHECK();
         ks = kd; vs = vd;
     }
@@ -322,7 +339,7 @@ GSX_API int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_i
     if (n == 0) return GSX_OK;
     if (!keys_in || !keys_out || !values_out || !keys_tmp || !values_tmp || !ws) return GSX_E_INVALID;
     if (keys_in == keys_out || keys_in == keys_tmp || keys_out == keys_tmp) return GSX_E_INVALID;
-    return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, begin_bit, end_bit,
+    return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, nullptr, begin_bit, end_bit,
                                ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -66,12 +66,19 @@ class _Scratch:
     """Per-device grow-only scratch for binning (instance buffers are sized by the data)."""
     def __init__(self):
         self.capacity = {}
+        self.pinned = {}
 
     def cap(self, dev, n):
         return self.capacity.get(dev, max(4 * n, 1 << 16))
 
     def grow(self, dev, d):
         self.capacity[dev] = int(d * 1.25) + 4096
+
+    def count_slot(self, dev):
+        """(pinned int64[1], event) for the asynchronous read-back of the instance count"""
+        if dev not in self.pinned:
+            self.pinned[dev] = (torch.zeros(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        return self.pinned[dev]
 
 
 _scratch = _Scratch()
@@ -149,6 +156,41 @@ def bin_instances(rec, tt, H, W):
     return offsets, bufs[0], bufs[1], ranges, chunk_base, int(D.value)
 
 
+def bin_count(tt):
+    """Enqueue scan(tiles_touched) and the asynchronous copy of the instance count to pinned host memory.
+    -> offsets, total_dev (device u64[1]), (pinned, event): the count is valid after event.synchronize()."""
+    lib = L.lib()
+    n = tt.numel(); dev = tt.device
+    offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    wsb = lib.gsx_scan_workspace_bytes(max(n, 1))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    pinned, ev = _scratch.count_slot(dev)
+    with _stage("bin_count"):
+        L.check(lib.gsx_bin_count(_ptr(tt), n, _ptr(offsets), _ptr(total), C.c_void_p(pinned.data_ptr()), _ptr(ws), wsb, _stream()),
+                "gsx_bin_count")
+    ev.record()
+    return offsets, total, (pinned, ev)
+
+
+def bin_emit_sort(rec, offsets, total, n, H, W, cap):
+    """Enqueue emit + sort + ranges + chunk table for at most `cap` instances (count read on the device).
+    -> tiles_sorted, ranks_sorted, ranges, chunk_base"""
+    lib = L.lib()
+    dev = rec.device
+    tw, th = (W + L.TILE - 1) // L.TILE, (H + L.TILE - 1) // L.TILE
+    ranges = torch.empty(tw * th, 2, dtype=torch.int32, device=dev)
+    chunk_base = torch.empty(tw * th + 1, dtype=torch.int32, device=dev)
+    bufs = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
+    wsb = lib.gsx_bin_workspace_bytes(n, cap)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with _stage("bin_emit_sort"):
+        L.check(lib.gsx_bin_emit_sort(_ptr(rec), _ptr(offsets), n, H, W, cap, _ptr(total), _ptr(bufs[0]), _ptr(bufs[1]),
+                                      _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), _ptr(ws), wsb, _stream()),
+                "gsx_bin_emit_sort")
+    return bufs[0], bufs[1], ranges, chunk_base
+
+
 _last_D = 0
 
 
@@ -187,9 +229,26 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
     if order is None:
         order = depth_order(keys)
     rec, tt, rank_of = build_records(pre, order, H, W)
-    offsets, tiles, ranks, ranges, chunk_base, D = bin_instances(rec, tt, H, W)
-    rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, D,
-                                                                          want_depth, need_bwd)
+    # Binning and compositing are enqueued against the buffers' CAPACITY; the instance count D reaches the host
+    # through pinned memory while the GPU is already sorting, so the stream never drains in the middle of a view
+    # (gsx_bin_instances, the synchronising form, idles the GPU for ~0.1 ms per view).  If D exceeds the capacity
+    # -- first view of a scene, or a sudden jump -- the truncated results are discarded and the tail is redone.
+    global _last_D
+    dev = rec.device
+    offsets, total, (pinned, ev) = bin_count(tt)
+    while True:
+        cap = _scratch.cap(dev, n)
+        tiles, ranks, ranges, chunk_base = bin_emit_sort(rec, offsets, total, n, H, W, cap)
+        rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, cap,
+                                                                              want_depth, need_bwd)
+        ev.synchronize()
+        D = int(pinned[0])
+        if D >= 0xFFFFFFFF:
+            raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
+        if D <= cap:
+            break
+        _scratch.grow(dev, D)
+    _last_D = D
     vs = ViewState()
     vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, order, rank_of, rec, tt, offsets
     vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = ranks, ranges, chunk_base, chunk_state, max_chunks

@@ -9,10 +9,11 @@ import torch
 DEFAULT_LRS = dict(positions=1e-4, features=1e-3, scales=1e-4, rotations=1e-4, opacity=1e-3)
 
 
-def make_optimizer(model, lrs=None, fused_clip_norm=None):
+def make_optimizer(model, lrs=None, fused_clip_norm=None, write_clipped_grad=False):
     """Adam with one group per tensor in the reference's order (trainer.py:49-61).
     fused_clip_norm = max_grad_norm selects the fused HIP clip+Adam step (optim.FusedClipAdam);
-    train_step then skips its own clip_grad_norm_ call."""
+    train_step then skips its own clip_grad_norm_ call.  write_clipped_grad=True also scales .grad in place
+    as clip_grad_norm_ does (the trainer never reads .grad after the step, so the default saves that write)."""
     lrs = dict(DEFAULT_LRS, **(lrs or {}))
     m = model.module if hasattr(model, "module") else model
     if fused_clip_norm is not None:
@@ -23,7 +24,7 @@ def make_optimizer(model, lrs=None, fused_clip_norm=None):
             {'params': m.scales, 'lr': lrs['scales']},
             {'params': m.rotations, 'lr': lrs['rotations']},
             {'params': m.opacity, 'lr': lrs['opacity']},
-        ], max_grad_norm=fused_clip_norm)
+        ], max_grad_norm=fused_clip_norm, write_clipped_grad=write_clipped_grad)
     return torch.optim.Adam([
         {'params': m.positions, 'lr': lrs['positions']},
         {'params': m.features, 'lr': lrs['features']},

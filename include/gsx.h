@@ -91,6 +91,22 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
                       int64_t capacity, uint32_t* offsets,
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                       uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
+/* The same binning in two asynchronous halves, for callers that must not stall the stream in the middle of a
+ * forward (the synchronising read-back above idles the GPU for the length of a host round trip).
+ * gsx_bin_count: offsets = exclusive scan of tiles_touched, *total_dev (device, u64) = instance count D;
+ *   if D_pinned_host != NULL the count is also copied there asynchronously (pinned host memory; valid once the
+ *   caller has synchronised on an event recorded after this call).  ws: gsx_scan_workspace_bytes(N).
+ * gsx_bin_emit_sort: everything after the count, with D read from *total_dev ON THE DEVICE and clamped to
+ *   `capacity` (which sizes the launches): no host synchronisation.  If D turns out to exceed capacity the
+ *   results are truncated (never out of bounds); the caller detects that from the count and calls again with
+ *   larger buffers.  ws: gsx_bin_workspace_bytes(N, capacity).  Size chunk_state / partials / launch grids from
+ *   capacity (gsx_max_chunks(capacity, H, W)), not from D. */
+int gsx_bin_count(const uint32_t* tiles_touched, int32_t N, uint32_t* offsets, uint64_t* total_dev,
+                  int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream);
+int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                      int64_t capacity, const uint64_t* total_dev,
+                      uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                      uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream);
 /* upper bound on the chunk count for D instances: D / GSX_CHUNK + min(D, n_tiles).  The caller sizes
  * chunk_state with it: max_chunks * GSX_STATE_WORDS * 256 floats. */
 int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);

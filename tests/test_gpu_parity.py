@@ -243,6 +243,40 @@ def test_module_dropin_matches_reference_outputs(dev):
     assert torch.equal(out2["rendered_images"], out["rendered_images"])
 
 
+@pytest.mark.parametrize("cap", [1, 777, 5000, 1 << 20])
+def test_async_binning_matches_synchronous(dev, cap):
+    """gsx_bin_count + gsx_bin_emit_sort (instance count read on the device, launches sized by capacity) against
+    gsx_bin_instances (host read-back): bit-equal products when the capacity suffices, truncated but in-bounds
+    results plus the true count when it does not; the render path then grows its buffers and redoes the view."""
+    from gaussian_splatting_amd import render as R
+    params = synth_scene(3000, 21, 0.004, 0.03)
+    H, W = 96, 80
+    gp = gpu_pipeline(params, pose_tz(2.0), H, W, dev)
+    t = gp["_t"]; n = 3000; D = gp["D"]
+    assert D > 5000
+    offsets, total, (pinned, ev) = R.bin_count(t["tt"])
+    tiles, ranks, ranges, chunk_base = R.bin_emit_sort(t["rec"], offsets, total, n, H, W, cap)
+    torch.cuda.synchronize()
+    assert int(pinned[0]) == D and int(total.item()) == D
+    assert np.array_equal(_u32(offsets)[:n], gp["offsets"])
+    if cap >= D:
+        assert np.array_equal(_u32(tiles)[:D], gp["tiles"]) and np.array_equal(_u32(ranks)[:D], gp["ranks"])
+        assert np.array_equal(_u32(ranges), gp["ranges"])
+        assert np.array_equal(_u32(chunk_base), _u32(t["chunk_base"]))
+    else:       # truncated: the first `cap` emitted instances, sorted; ranges partition [0, cap)
+        r = _u32(ranges)
+        assert r[0, 0] == 0 and r[-1, 1] == cap and np.all(r[1:, 0] == r[:-1, 1])
+        tk = _u32(tiles)[:cap]
+        assert np.all(tk[:-1] <= tk[1:])
+    # the render path recovers from a capacity that is too small
+    R._scratch.capacity[dev] = cap
+    outs, vs, _ = R.forward_view(t["P"], t["pose"], H, W)
+    torch.cuda.synchronize()
+    assert vs.D == D and R._scratch.cap(dev, n) >= D
+    assert np.array_equal(outs[0].cpu().numpy(), gp["rgb"])
+    R._scratch.capacity.pop(dev, None)
+
+
 def test_cpu_tensors_fail_loudly():
     from gaussian_splatting_amd import GaussianSplat
     m = GaussianSplat(8)
