@@ -161,7 +161,7 @@ template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t N, int H, int W, int tw, float stepx, float stepy,
-    const uint32_t* __restrict__ state, float* __restrict__ chunk_state)
+    const uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_rank[kCBatch];
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
     bool stop = false;
     uint32_t active = 0;
+    bool unit_opacity = true;                 // every staged opacity in [0, 1] (so |T| cannot grow inside the chunk)
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
         if (i < g.end) {
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
             const float4 a = R[0], b = R[1];
+            unit_opacity = unit_opacity && (b.y >= 0.0f) && (b.y <= 1.0f);
             float4 c = R[2];
             c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
@@ -231,6 +233,8 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         *state_ptr(chunk_state, chunk, 4, pix) = __int_as_float(e[k]);
         *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
     }
+    const bool all_unit = __builtin_amdgcn_ballot_w64(!unit_opacity) == 0ull;
+    if (lane == 0) chunk_meta[chunk] = all_unit ? GSX_META_UNIT_OPACITY : 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
-    const float* __restrict__ chunk_state, const float* __restrict__ d_rgb, float* __restrict__ partials)
+    const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
+    const float* __restrict__ d_rgb, float* __restrict__ partials)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
@@ -443,6 +448,35 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     }
     if (eff_end == g.begin) return;
     const int lane = threadIdx.x;
+    // Occlusion cut (the transmittance twin of the footprint cut): if every pixel of the tile enters this chunk
+    // with |T| < 2^-GSX_CUT_LOG2 and no opacity in the chunk lies outside [0, 1] (so |T| cannot grow inside it),
+    // every weight T*alpha of the chunk is below 2^-24 and so is every dL/dalpha per unit of upstream gradient:
+    // the rows are written as zeros without evaluating a pair.  T at the chunk's start = T at the end of the
+    // tile's previous chunk, which the forward left in the chunk state.  Half of a dense view's chunks go this way.
+    if (chunk > chunk_base[g.tile] && (chunk_meta[chunk] & GSX_META_UNIT_OPACITY)) {
+        const float* ps = chunk_state + (size_t)(chunk - 1) * GSX_STATE_WORDS * kPixPerTile;
+        bool dark = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int pix = k * 64 + lane;
+            const float pm = ps[6 * kPixPerTile + pix];
+            const int pe = __float_as_int(ps[7 * kPixPerTile + pix]);
+            dark = dark && (pm == 0.0f || pe <= -GSX_CUT_LOG2);          // |m| < 1  =>  |m| 2^e < 2^-24
+        }
+        if (__builtin_amdgcn_ballot_w64(!dark) == 0ull) {
+            for (uint32_t i = g.begin + lane; i < eff_end; i += 64) {
+                const uint32_t r = ranks[i];
+                const float2 bb = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rec) + (size_t)GSX_REC_FLOATS * r + 10);
+                const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
+                const int tx0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, tx1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;
+                const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
+                float* row = partials + (size_t)(offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0))) * 9u;
+#pragma unroll
+                for (int c = 0; c < 9; c++) row[c] = 0.0f;
+            }
+            return;
+        }
+    }
     const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
     float gx[2], gy[2];
     gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
@@ -555,23 +589,24 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     const float sx = lin_step(W), sy = lin_step(H);
     const float4* r4 = (const float4*)rec;
+    uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     GSX_HIP(hipMemsetAsync(state, 0, 16, st));
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
         tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
     } else {
-        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
         tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
     }
     saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
-            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
             tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
         } else {
-            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state);
+            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
             tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
         }
     }
@@ -592,7 +627,8 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
     chunk_bwd_kernel<<<dim3((unsigned)max_chunks), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
-        lin_step(W), lin_step(H), state, chunk_state, d_rgb, partials);
+        lin_step(W), lin_step(H), state, chunk_state,
+        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile), d_rgb, partials);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -609,4 +645,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 5; }
+GSX_API int gsx_abi_version(void) { return 6; }

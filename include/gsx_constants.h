@@ -41,6 +41,10 @@
  *  0..2 local colour (later: colour behind the chunk)  3,4 local transmittance (mantissa, exponent)
  *  5 local depth  6,7 transmittance at the chunk's end (mantissa, exponent) */
 #define GSX_STATE_WORDS 8
+/* the chunk-state buffer ends with one u32 per chunk (after max_chunks * GSX_STATE_WORDS * 256 floats):
+ * bit 0 = every opacity staged for the chunk lies in [0, 1].  The backward drops a chunk whose pixels all start
+ * with |T| < 2^-GSX_CUT_LOG2 only when that bit is set (then |T| cannot grow inside the chunk). */
+#define GSX_META_UNIT_OPACITY 1u
 
 /* "no saturation" marker for the per-pixel saturation rank */
 #define GSX_RANK_NONE 0xFFFFFFFFu

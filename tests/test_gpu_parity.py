@@ -277,6 +277,43 @@ def test_async_binning_matches_synchronous(dev, cap):
     R._scratch.capacity.pop(dev, None)
 
 
+def test_occlusion_cut_backward(dev, O):
+    """Tiles buried under thousands of near-opaque splats: most of their chunks start with T < 2^-24 and
+    the backward writes their rows as zeros (occlusion cut, gsx.h).  Gradients must still match the oracle, which
+    evaluates every pair, at the usual tolerance; the image is untouched by the cut."""
+    rng = np.random.default_rng(77)
+    n, H, W = 6000, 64, 64                         # no global exit (min alpha 0.96) but the 4 central tiles are buried
+    params = synth_scene(n, 78, 0.05, 0.2)
+    params["opacity"] = rng.uniform(0.6, 1.0, (n, 1)).astype(np.float32)
+    pose = pose_tz(2.0)
+    gp = gpu_pipeline(params, pose, H, W, dev)
+    fw = O.forward(params, pose, H, W, "tiled")
+    assert_integer_products_equal(gp, fw)
+    assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
+    # the cut must actually fire here: chunks whose predecessor ends with every pixel's exponent <= -24
+    t = gp["_t"]
+    cb = _u32(t["chunk_base"]).astype(np.int64); nch = int(cb[-1])
+    st = t["chunk_state"][: nch * 8 * 256].view(nch, 8, 256).cpu().numpy()
+    e_end = st[:, 7, :].view(np.int32); m_end = st[:, 6, :]
+    dark_end = np.all((m_end == 0) | (e_end <= -24), axis=1)
+    first = np.zeros(nch, bool); first[cb[:-1][cb[:-1] < nch]] = True
+    skipped = np.zeros(nch, bool); skipped[1:] = dark_end[:-1]; skipped &= ~first
+    assert skipped.mean() > 0.1, skipped.mean()
+    d_rgb = rng.standard_normal((3, H, W)).astype(np.float32)
+    g = gpu_backward(gp, H, W, d_rgb)
+    go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
+    for k in PARAMS:
+        assert rel_err(g[k], go[k]) < GRAD_RTOL, k
+    # out-of-range opacities switch the cut off for their chunks (|T| may grow inside them): still within tolerance
+    params["opacity"][::7] = 1.5
+    gp = gpu_pipeline(params, pose, H, W, dev)
+    fw = O.forward(params, pose, H, W, "tiled")
+    g = gpu_backward(gp, H, W, d_rgb)
+    go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
+    for k in PARAMS:
+        assert rel_err(g[k], go[k]) < GRAD_RTOL, k + " (opacity > 1)"
+
+
 def test_cpu_tensors_fail_loudly():
     from gaussian_splatting_amd import GaussianSplat
     m = GaussianSplat(8)
