@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--config", default="c3", help="scene config (c2/c3/c4/c5); the metric is quoted on c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time render fwd+bwd(+all-reduce) only")
+    ap.add_argument("--inference", action="store_true",
+                    help="informational: forward-only orbit rendering (SURVEY 8f N1, render_frames); not the headline metric")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the multi-GPU path on one GPU: init RCCL with world 1 and run the collectives anyway")
     ap.add_argument("--torch-optimizer", action="store_true",
@@ -110,7 +112,9 @@ def main():
 
     def step(s):
         v = (s * world + rank) % n_views
-        if args.no_optimizer:
+        if args.inference:
+            model.render_frames(poses[v:v + 1], (H, W))
+        elif args.no_optimizer:
             opt.zero_grad()
             out = net(poses[v:v + 1], (H, W))
             l1_loss(out, target).backward()
@@ -143,7 +147,7 @@ def main():
     timer = R.StageTimer() if rank == 0 else None
     R.set_stage_timer(timer)
     d_sum = 0
-    k_prof = min(args.steps, n_views)
+    k_prof = 0 if args.inference else min(args.steps, n_views)
     for s in range(k_prof):
         v = (s * world + rank) % n_views
         opt.zero_grad()
@@ -152,7 +156,7 @@ def main():
         l1_loss(out, target).backward()
     R.set_stage_timer(None)
     fence()
-    if rank == 0:
+    if rank == 0 and k_prof:
         tot = timer.totals_ms()
         d_avg = d_sum / k_prof
         stages = {k: round(t / c, 4) for k, (t, c) in tot.items()}
@@ -185,13 +189,14 @@ def main():
     if rank == 0:
         value = world * args.steps * H * W / dt / 1e6
         line = {
-            "metric": "fwd+bwd splat-render Mpixels/s @1M Gaussians 1024^2",
+            "metric": ("forward-only (inference) splat-render Mpixels/s @1M Gaussians 1024^2" if args.inference
+                       else "fwd+bwd splat-render Mpixels/s @1M Gaussians 1024^2"),
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, 60-view orbit (radius 4, elevation 45), "
                                    f"one trainer step per view per GPU"
-                                   + (" (render fwd+bwd only)" if args.no_optimizer else (" (fwd + L1 + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
+                                   + (" (INFERENCE: forward only, not the headline metric)" if args.inference else " (render fwd+bwd only)" if args.no_optimizer else (" (fwd + L1 + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
                                       else " (fwd + L1 + bwd + fused clip_grad_norm+Adam)")),
                        "views_per_step": world, "parallelism": f"dp{world} over views"},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,

@@ -6,7 +6,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from .render import render_views
+from .render import render_views, render_orbit
 
 
 class GaussianSplat(nn.Module):
@@ -77,6 +77,12 @@ class GaussianSplat(nn.Module):
         if self.render_depth_map:
             out['depth_map'] = dmap
         return out
+
+    @torch.no_grad()
+    def render_frames(self, camera_poses: torch.Tensor, image_size: Tuple[int, int]) -> torch.Tensor:
+        """Inference over V poses (V,4,4) -> (V,3,H,W): what the reference's orbit script gets from V calls of
+        `model(pose.unsqueeze(0), size)['rendered_images'][0]` (utils/visualization.py:343-347), in one call."""
+        return render_orbit(self.positions, self.scales, self.rotations, self.opacity, self.features, camera_poses, image_size)
 
     def last_n_composited(self):
         """Number of Gaussians composited before the global early exit (:147) in the last

@@ -337,3 +337,23 @@ def render_views(positions, scales, rotations, opacity, features, poses, image_s
     chunk-state word less per pixel in the compositing kernels; the depth_map output is then an empty tensor."""
     H, W = int(image_size[0]), int(image_size[1])
     return RenderFunction.apply(positions, scales, rotations, opacity, features, poses, H, W, want_depth)
+
+
+@torch.no_grad()
+def render_orbit(positions, scales, rotations, opacity, features, poses, image_size, out=None):
+    """the inference caller of the path (/root/reference/utils/visualization.py:343-347 renders an
+    orbit one `model(pose.unsqueeze(0), size)` call at a time).  Renders V poses (V,4,4) back to back into ONE
+    (V,3,H,W) tensor: no autograd node, no backward state (the combine pass skips its second scan and the chunk-end
+    transmittances), each view composited in its own depth order exactly as V separate forward calls would."""
+    if not positions.is_cuda:
+        raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
+                           "there is no CPU fallback")
+    H, W = int(image_size[0]), int(image_size[1])
+    params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
+    poses = _f32c(poses.detach().to(positions.device))
+    V = poses.shape[0]
+    frames = out if out is not None else torch.empty(V, 3, H, W, dtype=torch.float32, device=positions.device)
+    for v in range(V):
+        o, _, _ = forward_view(params, poses[v], H, W, want_depth=False, need_bwd=False)
+        frames[v].copy_(o[0])
+    return frames

@@ -314,6 +314,27 @@ def test_occlusion_cut_backward(dev, O):
         assert rel_err(g[k], go[k]) < GRAD_RTOL, k + " (opacity > 1)"
 
 
+def test_orbit_frames_equal_per_view_forward(dev, O):
+    """render_frames(V poses) == V module forwards (bitwise), and == the oracle within 1e-4."""
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.scenes import create_orbit_poses
+    n, H, W = 1500, 48, 40
+    params = synth_scene(n, 31, 0.01, 0.06)
+    m = GaussianSplat(n)
+    m.load_state_dict({k: torch.from_numpy(params[k]) for k in PARAMS})
+    m = m.to(dev).eval()
+    poses_np = create_orbit_poses(4.0, 6, 45.0)
+    poses = torch.from_numpy(poses_np).to(dev)
+    frames = m.render_frames(poses, (H, W))
+    assert frames.shape == (6, 3, H, W)
+    with torch.no_grad():
+        for v in range(6):
+            one = m(poses[v].unsqueeze(0), (H, W))["rendered_images"][0]
+            assert torch.equal(frames[v], one), v
+    fw = O.forward(params, poses_np[2], H, W, "tiled")
+    assert np.abs(frames[2].cpu().numpy() - fw["rgb"]).max() < RGB_TOL
+
+
 def test_cpu_tensors_fail_loudly():
     from gaussian_splatting_amd import GaussianSplat
     m = GaussianSplat(8)

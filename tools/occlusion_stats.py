@@ -37,3 +37,19 @@ for v in views:
         res[f"skip_chunks<{eps:.1e}"] = round(float(sk.float().mean()), 3)
         res[f"skip_inst<{eps:.1e}"] = round(float(inst_t[sk].sum()) / max(vs.D, 1), 3)
     print(json.dumps(res))
+    # forward level schemes: a chunk with local index j >= b is skipped iff its tile is dark by the last boundary b <= j
+    dark = (mx < 2.0 ** -24).cpu().numpy()
+    tiles = np.nonzero(lens)[0]
+    res2 = {}
+    for name, bounds in {"4,16": (4, 16), "8,24": (8, 24), "2,6,14,30": (2, 6, 14, 30), "4,12,28": (4, 12, 28), "8": (8,), "16": (16,)}.items():
+        sk = 0
+        for t in tiles:
+            c0, c1 = cb[t], cb[t + 1]; nc = c1 - c0
+            d = dark[c0:c1]                      # d[j]: tile dark at the START of local chunk j
+            for bi, b in enumerate(bounds):
+                if b >= nc: break
+                hi = bounds[bi + 1] if bi + 1 < len(bounds) else nc
+                if d[b]:
+                    sk += nc - b; break
+        res2[name] = round(sk / nch, 3)
+    print(json.dumps({"view": v, "fwd_skippable_by_levels": res2, "ideal": round(float(dark.mean()), 3)}))
