@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
-    uint32_t* __restrict__ state, float* __restrict__ chunk_state,
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_dark,
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
@@ -272,6 +272,14 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = cb + u;
             if (c < c1) {
+                if (need_bwd) {
+                    // occlusion cut: byte w of chunk_dark[c] = 1 when every pixel of quadrant w (this wave's 64 pixels)
+                    // enters chunk c with |T| < 2^-GSX_CUT_LOG2 (|m| < 1 after renorm, so e <= -24 suffices); pixels
+                    // outside the image carry no gradient and count as dark
+                    const bool darkp = !inside || m == 0.0f || e <= -GSX_CUT_LOG2;
+                    const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
+                    if ((threadIdx.x & 63) == 0) reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = all_dark ? 1 : 0;
+                }
                 const float Tv = ldexpf(m, e);
                 C0 += Tv * l0[u]; C1 += Tv * l1[u]; C2 += Tv * l2[u];
                 if (DEPTH) Dm += Tv * l5[u];
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
-    const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
+    const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
     const float* __restrict__ d_rgb, float* __restrict__ partials)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
@@ -448,22 +456,19 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     }
     if (eff_end == g.begin) return;
     const int lane = threadIdx.x;
-    // Occlusion cut (the transmittance twin of the footprint cut): if every pixel of the tile enters this chunk
+    // Occlusion cut (the transmittance twin of the footprint cut): if every pixel of a quadrant enters this chunk
     // with |T| < 2^-GSX_CUT_LOG2 and no opacity in the chunk lies outside [0, 1] (so |T| cannot grow inside it),
-    // every weight T*alpha of the chunk is below 2^-24 and so is every dL/dalpha per unit of upstream gradient:
-    // the rows are written as zeros without evaluating a pair.  T at the chunk's start = T at the end of the
-    // tile's previous chunk, which the forward left in the chunk state.  Half of a dense view's chunks go this way.
-    if (chunk > chunk_base[g.tile] && (chunk_meta[chunk] & GSX_META_UNIT_OPACITY)) {
-        const float* ps = chunk_state + (size_t)(chunk - 1) * GSX_STATE_WORDS * kPixPerTile;
-        bool dark = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int pix = k * 64 + lane;
-            const float pm = ps[6 * kPixPerTile + pix];
-            const int pe = __float_as_int(ps[7 * kPixPerTile + pix]);
-            dark = dark && (pm == 0.0f || pe <= -GSX_CUT_LOG2);          // |m| < 1  =>  |m| 2^e < 2^-24
-        }
-        if (__builtin_amdgcn_ballot_w64(!dark) == 0ull) {
+    // every weight T*alpha there is below 2^-24 and so is every dL/dalpha per unit of upstream gradient: the
+    // quadrant is masked out for the whole chunk, and a chunk with four dark quadrants writes its rows as zeros
+    // without evaluating a pair.  Half of a dense view's chunks go this way.
+    // chunk_dark[chunk]: one byte per 8x8 quadrant, written by the combine pass; only trusted for unit-opacity chunks
+    uint32_t dark_mask = 0;
+    if (chunk_meta[chunk] & GSX_META_UNIT_OPACITY) {
+        const uint32_t dw = chunk_dark[chunk];
+        dark_mask = (dw & 1u) | ((dw >> 7) & 2u) | ((dw >> 14) & 4u) | ((dw >> 21) & 8u);
+    }
+    {
+        if (dark_mask == 0xFu) {
             for (uint32_t i = g.begin + lane; i < eff_end; i += 64) {
                 const uint32_t r = ranks[i];
                 const float2 bb = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rec) + (size_t)GSX_REC_FLOATS * r + 10);
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         for (uint32_t j = cnt; j-- > 0; ) {
             slot -= 36u;                                      // byte offset into s_red
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
-            if (mk == 0u) {                                   // inside the tile's box but outside the ellipse: a zero row
+            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z)) & ~dark_mask;
+            if (mk == 0u) {                                   // inside the tile's box but outside the ellipse (or occluded): a zero row
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(s_red) + slot) = 0.f;
                 continue;
             }
@@ -595,19 +600,19 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
     } else {
         if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
     }
     saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
         } else {
             chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, rgb, alpha, depth_map);
+            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
         }
     }
     GSX_LAUNCH_CHECK();
@@ -628,7 +633,8 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     chunk_bwd_kernel<<<dim3((unsigned)max_chunks), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state,
-        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile), d_rgb, partials);
+        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile),
+        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + max_chunks, d_rgb, partials);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

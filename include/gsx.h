@@ -108,7 +108,7 @@ int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int3
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                       uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream);
 /* upper bound on the chunk count for D instances: D / GSX_CHUNK + min(D, n_tiles).  The caller sizes
- * chunk_state with it: max_chunks * (GSX_STATE_WORDS * 256 + 1) floats (the last max_chunks words are the
+ * chunk_state with it: max_chunks * (GSX_STATE_WORDS * 256 + 2) floats (the last 2 * max_chunks words are the
  * per-chunk meta words, gsx_constants.h). */
 int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
 
@@ -121,7 +121,7 @@ int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
  * exit fired before the last Gaussian.
  *   state (4 x u32, out): state[0] = exit rank k* (GSX_RANK_NONE: no exit), state[1] = 1 if some
  *       pixel is unsaturated.  Ranks 0..k* are composited.
- *   chunk_state: max_chunks * (GSX_STATE_WORDS * 256 + 1) floats; with need_bwd = 1 it is left holding
+ *   chunk_state: max_chunks * (GSX_STATE_WORDS * 256 + 2) floats; with need_bwd = 1 it is left holding
  *       what gsx_composite_bwd needs (per chunk and pixel: colour behind the chunk, transmittance
  *       at its end).
  *   rgb (3,H,W), alpha (H,W) accumulated alpha, depth_map (H,W) or NULL. */
@@ -135,9 +135,9 @@ int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint
  * per-splat partial sums over the wavefront (DPP) and stores ONE row per (tile, rank) instance at
  * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
  * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
- * Occlusion cut: a chunk that every pixel of its tile enters with |T| < 2^-GSX_CUT_LOG2, and whose opacities all
- * lie in [0, 1], gets zero rows without evaluating a pair (all its weights T*alpha are below 2^-24, like the
- * pairs the footprint cut drops).
+ * Occlusion cut: an 8x8 quadrant that all its pixels enter a chunk with |T| < 2^-GSX_CUT_LOG2 is masked out for
+ * that chunk if the chunk's opacities all lie in [0, 1] (all its weights T*alpha are below 2^-24, like the pairs
+ * the footprint cut drops); a chunk with four dark quadrants gets zero rows without evaluating a pair.
  *   partials: >= D rows of 9 floats. */
 int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
                       const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,

@@ -41,9 +41,11 @@
  *  0..2 local colour (later: colour behind the chunk)  3,4 local transmittance (mantissa, exponent)
  *  5 local depth  6,7 transmittance at the chunk's end (mantissa, exponent) */
 #define GSX_STATE_WORDS 8
-/* the chunk-state buffer ends with one u32 per chunk (after max_chunks * GSX_STATE_WORDS * 256 floats):
- * bit 0 = every opacity staged for the chunk lies in [0, 1].  The backward drops a chunk whose pixels all start
- * with |T| < 2^-GSX_CUT_LOG2 only when that bit is set (then |T| cannot grow inside the chunk). */
+/* the chunk-state buffer ends with two u32 arrays of max_chunks entries (after max_chunks * GSX_STATE_WORDS * 256
+ * floats): flags (bit 0 = every opacity staged for the chunk lies in [0, 1]; written by the chunk pass) and dark
+ * bytes (byte w = 1 when every pixel of 8x8 quadrant w enters the chunk with |T| < 2^-GSX_CUT_LOG2; written by the
+ * combine pass).  The backward masks a dark quadrant out only when the flag is set (then |T| cannot grow inside
+ * the chunk). */
 #define GSX_META_UNIT_OPACITY 1u
 
 /* "no saturation" marker for the per-pixel saturation rank */
