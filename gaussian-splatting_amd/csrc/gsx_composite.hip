@@ -246,7 +246,8 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
-    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_dark,
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
+    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, uint32_t max_chunks,
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     // chunk states are independent loads: fetch kCombineBatch chunks ahead of the dependent scan so that the
     // longest tile (tens of chunks) is not one memory latency per chunk
     constexpr int kCombineBatch = 16;
+    __shared__ uint8_t s_dark[kCombineBatch][4];
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch], l5[kCombineBatch];
 #pragma unroll
@@ -278,7 +280,10 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                     // outside the image carry no gradient and count as dark
                     const bool darkp = !inside || m == 0.0f || e <= -GSX_CUT_LOG2;
                     const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
-                    if ((threadIdx.x & 63) == 0) reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = all_dark ? 1 : 0;
+                    if ((threadIdx.x & 63) == 0) {
+                        reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = all_dark ? 1 : 0;
+                        s_dark[u][threadIdx.x >> 6] = all_dark ? 1 : 0;
+                    }
                 }
                 const float Tv = ldexpf(m, e);
                 C0 += Tv * l0[u]; C1 += Tv * l1[u]; C2 += Tv * l2[u];
@@ -288,6 +293,23 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                 renorm(m, e);
                 if (need_bwd) { *state_ptr(chunk_state, c, 6, pix) = m; *state_ptr(chunk_state, c, 7, pix) = __int_as_float(e); }
             }
+        }
+        if (need_bwd) {
+            // Work list of the backward: chunks that need arithmetic from the front of `perm`, fully occluded chunks
+            // (zero rows only) from its back, so that the dispatcher hands out the long work items first and the
+            // trivial ones fill the tail.  The order inside each part depends on timing; the results do not (every
+            // chunk writes its own rows).
+            __syncthreads();
+            const uint32_t c = cb + threadIdx.x;
+            if (threadIdx.x < kCombineBatch && c < c1) {
+                uint32_t* cnt = work + (PASS1 ? 2 : 0);
+                uint32_t* perm = work + 4 + (PASS1 ? max_chunks : 0u);
+                const bool occluded = (chunk_meta[c] & GSX_META_UNIT_OPACITY) &&
+                                      (s_dark[threadIdx.x][0] & s_dark[threadIdx.x][1] & s_dark[threadIdx.x][2] & s_dark[threadIdx.x][3]);
+                if (occluded) perm[max_chunks - 1u - atomicAdd(cnt + 1, 1u)] = c;
+                else perm[atomicAdd(cnt, 1u)] = c;
+            }
+            __syncthreads();
         }
     }
     const float A = 1.0f - ldexpf(m, e);
@@ -435,17 +457,20 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
-    const float* __restrict__ d_rgb, float* __restrict__ partials)
+    const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
     // raw sums per staged splat: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy (dq = dL/dalpha * alpha), w*G0..2;
     // the second half is a dump area for the lanes that hold no sum (one bank each)
     __shared__ float s_red[2 * kCBatch * 9 + 64];
-    const uint32_t n_chunks = chunk_base[n_tiles];
-    if (blockIdx.x >= n_chunks) return;
-    const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
+    // work list left by the combine pass (gridDim.x == max_chunks): [0, n_work) chunks with arithmetic, the last
+    // n_occluded entries the fully occluded ones; the second list is the one rebuilt after a global early exit
     const uint32_t limit = rank_limit_from_state(state, N);
+    const uint32_t* cnt = work + (limit < N ? 2 : 0);
+    const uint32_t* perm = work + 4 + (limit < N ? gridDim.x : 0u);
+    if (blockIdx.x >= cnt[0] && blockIdx.x < gridDim.x - cnt[1]) return;
+    const uint32_t chunk = perm[blockIdx.x];
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
     // instances of this chunk that were composited: ranks ascend, keep those below the exit rank
     uint32_t eff_end = g.end;
@@ -597,22 +622,24 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     GSX_HIP(hipMemsetAsync(state, 0, 16, st));
+    uint32_t* work = meta + 2 * (size_t)max_chunks;          // 4 counters, two work lists of max_chunks
+    GSX_HIP(hipMemsetAsync(work, 0, 16, st));
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
+        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
     } else {
         if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
+        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
     }
     saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
+            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
         } else {
             chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
-            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta + max_chunks, rgb, alpha, depth_map);
+            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
         }
     }
     GSX_LAUNCH_CHECK();
@@ -634,7 +661,9 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state,
         reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile),
-        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + max_chunks, d_rgb, partials);
+        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + max_chunks,
+        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + 2 * (size_t)max_chunks,
+        d_rgb, partials);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -45,7 +45,8 @@
  * floats): flags (bit 0 = every opacity staged for the chunk lies in [0, 1]; written by the chunk pass) and dark
  * bytes (byte w = 1 when every pixel of 8x8 quadrant w enters the chunk with |T| < 2^-GSX_CUT_LOG2; written by the
  * combine pass).  The backward masks a dark quadrant out only when the flag is set (then |T| cannot grow inside
- * the chunk). */
+ * the chunk).  Behind them: 4 u32 counters and two work lists of max_chunks chunk ids each (chunks with arithmetic
+ * from the front, fully occluded chunks from the back; the second list is used after a global early exit). */
 #define GSX_META_UNIT_OPACITY 1u
 
 /* "no saturation" marker for the per-pixel saturation rank */
