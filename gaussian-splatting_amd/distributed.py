@@ -87,8 +87,12 @@ class DataParallelSplat(torch.nn.Module):
         self.last_sync_was_flat = not packed
         if packed:
             flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
+        if flat.is_cuda and dist.get_backend(self.group) == "nccl":
+            # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                   # gloo (CPU tests) has no AVG
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.mul_(1.0 / self.world)
         self.last_allreduce_bytes = flat.numel() * flat.element_size()
         if packed:
             off = 0
