@@ -260,8 +260,10 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     // longest tile (tens of chunks) is not one memory latency per chunk
     constexpr int kCombineBatch = 16;
     __shared__ uint8_t s_dark[kCombineBatch][4];
+    // the last batch's local results stay in registers for the backward scan (most tiles have one batch)
+    float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch];
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
-        float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch], l5[kCombineBatch];
+        float l5[kCombineBatch];
 #pragma unroll
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = min(cb + u, c1 - 1);
@@ -300,14 +302,27 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             // trivial ones fill the tail.  The order inside each part depends on timing; the results do not (every
             // chunk writes its own rows).
             __syncthreads();
-            const uint32_t c = cb + threadIdx.x;
-            if (threadIdx.x < kCombineBatch && c < c1) {
+            if (threadIdx.x < 64) {                       // wave 0: one atomic per class per batch, not per chunk
+                const uint32_t c = cb + threadIdx.x;
+                const bool valid = threadIdx.x < kCombineBatch && c < c1;
                 uint32_t* cnt = work + (PASS1 ? 2 : 0);
                 uint32_t* perm = work + 4 + (PASS1 ? max_chunks : 0u);
-                const bool occluded = (chunk_meta[c] & GSX_META_UNIT_OPACITY) &&
+                bool occluded = false;
+                if (valid) occluded = (chunk_meta[c] & GSX_META_UNIT_OPACITY) &&
                                       (s_dark[threadIdx.x][0] & s_dark[threadIdx.x][1] & s_dark[threadIdx.x][2] & s_dark[threadIdx.x][3]);
-                if (occluded) perm[max_chunks - 1u - atomicAdd(cnt + 1, 1u)] = c;
-                else perm[atomicAdd(cnt, 1u)] = c;
+                const unsigned long long m_occ = __builtin_amdgcn_ballot_w64(valid && occluded);
+                const unsigned long long m_work = __builtin_amdgcn_ballot_w64(valid && !occluded);
+                const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+                uint32_t b_occ = 0, b_work = 0;
+                if (threadIdx.x == 0) {
+                    if (m_occ) b_occ = atomicAdd(cnt + 1, (uint32_t)__popcll(m_occ));
+                    if (m_work) b_work = atomicAdd(cnt, (uint32_t)__popcll(m_work));
+                }
+                b_occ = __builtin_amdgcn_readfirstlane(b_occ); b_work = __builtin_amdgcn_readfirstlane(b_work);
+                if (valid) {
+                    if (occluded) perm[max_chunks - 1u - (b_occ + (uint32_t)__popcll(m_occ & lt))] = c;
+                    else perm[b_work + (uint32_t)__popcll(m_work & lt)] = c;
+                }
             }
             __syncthreads();
         }
@@ -322,12 +337,23 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     if (!PASS1) {
         // a pixel at least 1e-5 below the threshold is unsaturated in any arithmetic
         const bool unsat = inside && !(A > GSX_SAT_ALPHA - 1e-5f);
-        if (__syncthreads_or(unsat) && threadIdx.x == 0) atomicOr(state + 1, 1u);
+        // thousands of tiles raise the same flag: look before the atomic (4096 same-address atomics serialise in L2)
+        if (__syncthreads_or(unsat) && threadIdx.x == 0 &&
+            __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(state + 1, 1u);
     }
-    if (need_bwd) {
+    if (need_bwd && c1 > c0) {
         float B0 = 0.f, B1 = 0.f, B2 = 0.f;
-        for (uint32_t ce = c1; ce > c0; ce -= min((uint32_t)kCombineBatch, ce - c0)) {
-            float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch];
+        const uint32_t cbl = c0 + ((c1 - c0 - 1u) / kCombineBatch) * kCombineBatch;    // first chunk of the last forward batch
+#pragma unroll
+        for (int u = kCombineBatch - 1; u >= 0; u--) {
+            const uint32_t c = cbl + u;
+            if (c < c1) {
+                const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
+                *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
+                B0 = l0[u] + Tl * B0; B1 = l1[u] + Tl * B1; B2 = l2[u] + Tl * B2;
+            }
+        }
+        for (uint32_t ce = cbl; ce > c0; ce -= kCombineBatch) {                          // earlier batches: full, reloaded
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
                 const uint32_t c = (ce - c0 > (uint32_t)u) ? ce - 1 - u : c0;
