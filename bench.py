@@ -165,7 +165,7 @@ def main():
         alg = algorithmic_bytes(dom, n, d_avg, H * W)
         ach = alg / (stages[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_bytes(dom),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_bytes(dom) if args.config == "c3" else None,
                     "algorithmic_bytes_per_launch": int(alg),
                     "avg_launch_ms": stages[dom], "avg_instances_D": int(d_avg),
                     "note": "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
