@@ -155,7 +155,48 @@ def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, 
           f"max|rgb|={np.abs(img).max():.4f} -> {os.path.getsize(path)/1024:.0f} KiB", flush=True)
 
 
+def run_train_case(name, model, poses, H, W, seed_target, steps=3):
+    """the trainer step of /root/reference/training/trainer.py:133-178 around the
+    reference render -- zero_grad, forward, loss, backward, clip_grad_norm_(0.1), Adam with the five per-tensor
+    learning rates of configs/default_config.yaml:12-16 in the order of trainer.py:49-61 -- with the importable-math
+    subset of model/loss.py:89-109 as the loss (clamped MSE + scale and opacity regularisers; the VGG/LPIPS terms
+    need network weights).  Stores parameters before and after every step, the losses and the first step's
+    clipped gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(seed_target)
+    target = torch.rand(1, 3, H, W, generator=g)
+    poses_t = poses if torch.is_tensor(poses) else torch.from_numpy(poses)
+    fx = {k: getattr(model, k).detach().numpy().copy() for k in ("positions", "scales", "rotations", "opacity", "features")}
+    opt = torch.optim.Adam([
+        {'params': model.positions, 'lr': 1e-4}, {'params': model.features, 'lr': 1e-3},
+        {'params': model.scales, 'lr': 1e-4}, {'params': model.rotations, 'lr': 1e-4},
+        {'params': model.opacity, 'lr': 1e-3}])
+    losses, norms = [], []
+    for s in range(steps):
+        opt.zero_grad()
+        out = model(poses_t, (H, W))
+        c = torch.clamp(out['rendered_images'], 1e-8, 1.0 - 1e-8)
+        o = out['opacity']
+        loss = F.mse_loss(c, target) + 5e-4 * torch.mean(torch.norm(out['scales'], dim=-1)) + 5e-3 * torch.mean(o * (1 - o))
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)))
+        if s == 0:
+            for k in ("positions", "scales", "rotations", "opacity", "features"):
+                fx["clipped_g_" + k] = getattr(model, k).grad.detach().numpy().copy()
+        opt.step()
+        losses.append(float(loss))
+        for k in ("positions", "scales", "rotations", "opacity", "features"):
+            fx[f"after{s + 1}_{k}"] = getattr(model, k).detach().numpy().copy()
+    fx.update(poses=poses_t.numpy(), H=np.int64(H), W=np.int64(W), target=target.numpy(), losses=np.array(losses, np.float64),
+              grad_norms=np.array(norms, np.float64), steps=np.int64(steps), torch_version=np.array(torch.__version__))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"{name}: losses {losses} grad norms {norms}")
+
+
 def main():
+    if "--train-only" in sys.argv:
+        run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
+        return
     big = "--big" in sys.argv
     I3 = pose_tz(3.0)[None]
     run_case("n1_8x8", scene_default(1, 11), I3, 8, 8, 101)
@@ -172,6 +213,7 @@ def main():
     run_case("opac_out_of_range_64", scene_synth(64, 22, 0.01, 0.05, o_lo=-0.3, o_hi=1.4), pose_tz(2.0)[None], 24, 32, 110)
     run_case("h1_w5_n8", scene_synth(8, 23, 0.05, 0.2), pose_tz(2.0)[None], 1, 5, 111)
     run_case("odd_33x17_n120", scene_synth(120, 24, 0.01, 0.08), pose_tz(1.5)[None], 17, 33, 112)
+    run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
     if big:
         # BASELINE config 1: 5000 default-init Gaussians, 400x300 (README.md:85-94); ~16 GB RSS, ~10 s
         run_case("config1_5000_400x300", scene_default(5000, 0), I3, 300, 400, 0,

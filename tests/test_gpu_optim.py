@@ -90,3 +90,37 @@ def test_fused_image_loss_rejects_cpu():
     from gaussian_splatting_amd import loss as gl
     with pytest.raises(RuntimeError):
         gl.l1(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_trainer_three_steps_match_reference(fused):
+    """three trainer steps (zero_grad, forward, loss, backward, clip_grad_norm_(0.1), Adam with the
+    reference's five learning rates) on the reference itself (tests/golden/train3_400_32x24.npz, made by
+    make_golden.py::run_train_case) against the same steps through this path (fused HIP clip+Adam and loss, or torch's).
+    Bars: losses 1e-5 relative; first step's clipped gradients 1e-3 of the tensor's max; parameters after each step
+    within 2 % of ONE step's travel (lr) for 99 % of the elements -- Adam normalises every gradient to ~lr, so an
+    element whose reference gradient is rounding noise (a pair below the 2^-24 footprint cut) may move by a fraction
+    of lr where this path leaves it still; such elements are bounded by lr per step."""
+    import os
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.trainer import make_optimizer, train_step, reference_regularised_mse, DEFAULT_LRS
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "train3_400_32x24.npz")))
+    dev = torch.device("cuda:0")
+    names = ["positions", "scales", "rotations", "opacity", "features"]
+    m = GaussianSplat(400)
+    m.load_state_dict({k: torch.from_numpy(fx[k]) for k in names})
+    m = m.to(dev)
+    opt = make_optimizer(m, fused_clip_norm=0.1 if fused else None, write_clipped_grad=True)
+    poses = torch.from_numpy(fx["poses"]).to(dev); target = torch.from_numpy(fx["target"]).to(dev)
+    for s in range(int(fx["steps"])):
+        loss = train_step(m, opt, poses, target, reference_regularised_mse, max_grad_norm=0.1)
+        assert abs(float(loss) - fx["losses"][s]) <= 1e-5 * abs(fx["losses"][s]), (s, float(loss), fx["losses"][s])
+        if s == 0:
+            for k in names:
+                g, gr = getattr(m, k).grad.cpu().numpy(), fx["clipped_g_" + k]
+                assert np.abs(g - gr).max() <= 1e-3 * np.abs(gr).max(), k
+        for k in names:
+            d = np.abs(getattr(m, k).detach().cpu().numpy() - fx[f"after{s + 1}_{k}"]).ravel()
+            lr = DEFAULT_LRS[k]
+            assert np.quantile(d, 0.99) <= 0.02 * lr, (s, k, float(np.quantile(d, 0.99)), lr)
+            assert d.max() <= (s + 1) * lr * 1.01, (s, k, float(d.max()))
