@@ -25,6 +25,16 @@
 namespace gsx {
 
 constexpr int kCBatch = 64;            // records staged per LDS batch (one per lane)
+// backward work lists: classes 0..3 by expected cost (quadrant evaluations the forward counted, scaled by the
+// share of quadrants that are not occluded), class 4 = fully occluded (zero rows only).  Layout behind the flag
+// and dark words: 16 counters (two sets of 8: normal pass / pass after a global early exit), then for each set
+// kWorkClasses lists of max_chunks chunk ids.
+constexpr int kWorkClasses = 5;
+__device__ __forceinline__ uint32_t* work_counters(uint32_t* work, bool pass1) { return work + (pass1 ? 8 : 0); }
+__device__ __forceinline__ uint32_t* work_list(uint32_t* work, bool pass1, int cls, uint32_t max_chunks)
+{
+    return work + 16 + ((size_t)(pass1 ? kWorkClasses : 0) + (size_t)cls) * max_chunks;
+}
 constexpr int kPixPerTile = GSX_TILE * GSX_TILE;
 
 __device__ __forceinline__ float pix_coord(int i, int steps, float step)
@@ -184,6 +194,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     bool stop = false;
     uint32_t active = 0;
     bool unit_opacity = true;                 // every staged opacity in [0, 1] (so |T| cannot grow inside the chunk)
+    uint32_t cost = 0;                        // quadrant evaluations of this chunk (the backward's cost estimate)
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
         if (i < g.end) {
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
             const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
             if (mk == 0u) continue;                           // inside the tile's box but outside the ellipse
+            cost += (uint32_t)__builtin_popcount(mk);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (mk & (1u << k)) {
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
     }
     const bool all_unit = __builtin_amdgcn_ballot_w64(!unit_opacity) == 0ull;
-    if (lane == 0) chunk_meta[chunk] = all_unit ? GSX_META_UNIT_OPACITY : 0u;
+    if (lane == 0) chunk_meta[chunk] = (all_unit ? GSX_META_UNIT_OPACITY : 0u) | (cost << GSX_META_COST_SHIFT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -297,31 +309,30 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             }
         }
         if (need_bwd) {
-            // Work list of the backward: chunks that need arithmetic from the front of `perm`, fully occluded chunks
-            // (zero rows only) from its back, so that the dispatcher hands out the long work items first and the
-            // trivial ones fill the tail.  The order inside each part depends on timing; the results do not (every
-            // chunk writes its own rows).
+            // Work lists of the backward, by expected cost, so that the dispatcher hands out the long work items
+            // first and the trivial ones (occluded chunks: zero rows only) fill the tail.  The order inside a
+            // list depends on timing; the results do not (every chunk writes its own rows).
             __syncthreads();
             if (threadIdx.x < 64) {                       // wave 0: one atomic per class per batch, not per chunk
                 const uint32_t c = cb + threadIdx.x;
                 const bool valid = threadIdx.x < kCombineBatch && c < c1;
-                uint32_t* cnt = work + (PASS1 ? 2 : 0);
-                uint32_t* perm = work + 4 + (PASS1 ? max_chunks : 0u);
-                bool occluded = false;
-                if (valid) occluded = (chunk_meta[c] & GSX_META_UNIT_OPACITY) &&
-                                      (s_dark[threadIdx.x][0] & s_dark[threadIdx.x][1] & s_dark[threadIdx.x][2] & s_dark[threadIdx.x][3]);
-                const unsigned long long m_occ = __builtin_amdgcn_ballot_w64(valid && occluded);
-                const unsigned long long m_work = __builtin_amdgcn_ballot_w64(valid && !occluded);
-                const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
-                uint32_t b_occ = 0, b_work = 0;
-                if (threadIdx.x == 0) {
-                    if (m_occ) b_occ = atomicAdd(cnt + 1, (uint32_t)__popcll(m_occ));
-                    if (m_work) b_work = atomicAdd(cnt, (uint32_t)__popcll(m_work));
-                }
-                b_occ = __builtin_amdgcn_readfirstlane(b_occ); b_work = __builtin_amdgcn_readfirstlane(b_work);
+                int cls = -1;
                 if (valid) {
-                    if (occluded) perm[max_chunks - 1u - (b_occ + (uint32_t)__popcll(m_occ & lt))] = c;
-                    else perm[b_work + (uint32_t)__popcll(m_work & lt)] = c;
+                    const uint32_t meta = chunk_meta[c];
+                    const uint32_t n_dark = (meta & GSX_META_UNIT_OPACITY)
+                        ? (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]) : 0u;
+                    const uint32_t est = (meta >> GSX_META_COST_SHIFT) * (4u - n_dark);      // <= 4 * 4 * GSX_CHUNK
+                    cls = n_dark == 4u ? 4 : est >= 10u * GSX_CHUNK ? 0 : est >= 6u * GSX_CHUNK ? 1 : est >= 3u * GSX_CHUNK ? 2 : 3;
+                }
+                const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+                uint32_t* cnt = work_counters(work, PASS1);
+#pragma unroll
+                for (int k = 0; k < kWorkClasses; k++) {
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == k);
+                    uint32_t base = 0;
+                    if (threadIdx.x == 0 && mk) base = atomicAdd(cnt + k, (uint32_t)__popcll(mk));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (cls == k) work_list(work, PASS1, k, max_chunks)[base + (uint32_t)__popcll(mk & lt)] = c;
                 }
             }
             __syncthreads();
@@ -490,13 +501,16 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     // raw sums per staged splat: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy (dq = dL/dalpha * alpha), w*G0..2;
     // the second half is a dump area for the lanes that hold no sum (one bank each)
     __shared__ float s_red[2 * kCBatch * 9 + 64];
-    // work list left by the combine pass (gridDim.x == max_chunks): [0, n_work) chunks with arithmetic, the last
-    // n_occluded entries the fully occluded ones; the second list is the one rebuilt after a global early exit
+    // work lists left by the combine pass (gridDim.x == max_chunks), costliest class first, occluded chunks last;
+    // the second set is the one rebuilt after a global early exit
     const uint32_t limit = rank_limit_from_state(state, N);
-    const uint32_t* cnt = work + (limit < N ? 2 : 0);
-    const uint32_t* perm = work + 4 + (limit < N ? gridDim.x : 0u);
-    if (blockIdx.x >= cnt[0] && blockIdx.x < gridDim.x - cnt[1]) return;
-    const uint32_t chunk = perm[blockIdx.x];
+    const bool after_exit = limit < N;
+    const uint32_t* cnt = work_counters(const_cast<uint32_t*>(work), after_exit);
+    uint32_t b = blockIdx.x;
+    int cls = 0;
+    while (cls < kWorkClasses && b >= cnt[cls]) { b -= cnt[cls]; cls++; }       // costliest class first
+    if (cls == kWorkClasses) return;
+    const uint32_t chunk = work_list(const_cast<uint32_t*>(work), after_exit, cls, gridDim.x)[b];
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
     // instances of this chunk that were composited: ranks ascend, keep those below the exit rank
     uint32_t eff_end = g.end;
@@ -648,8 +662,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     GSX_HIP(hipMemsetAsync(state, 0, 16, st));
-    uint32_t* work = meta + 2 * (size_t)max_chunks;          // 4 counters, two work lists of max_chunks
-    GSX_HIP(hipMemsetAsync(work, 0, 16, st));
+    uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
+    GSX_HIP(hipMemsetAsync(work, 0, 64, st));
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
@@ -706,4 +720,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 6; }
+GSX_API int gsx_abi_version(void) { return 7; }

@@ -207,7 +207,7 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
     dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
     state = torch.empty(4, dtype=torch.int32, device=dev)
     max_chunks = int(lib.gsx_max_chunks(D, H, W))
-    chunk_state = torch.empty(max(max_chunks, 1) * (L.STATE_WORDS * 256 + 4) + 4, dtype=torch.float32, device=dev)
+    chunk_state = torch.empty(max(max_chunks, 1) * (L.STATE_WORDS * 256 + 12) + 16, dtype=torch.float32, device=dev)
     with _stage("composite_fwd"):
         L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), _ptr(chunk_base), n, H, W,
                                       max_chunks, _ptr(chunk_state), 1 if need_bwd else 0, _ptr(state),

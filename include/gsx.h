@@ -108,7 +108,7 @@ int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int3
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                       uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream);
 /* upper bound on the chunk count for D instances: D / GSX_CHUNK + min(D, n_tiles).  The caller sizes
- * chunk_state with it: max_chunks * (GSX_STATE_WORDS * 256 + 4) + 4 floats (the tail holds the per-chunk
+ * chunk_state with it: GSX_CHUNK_STATE_FLOATS(max_chunks) floats (the tail holds the per-chunk
  * meta words and the backward work lists, gsx_constants.h). */
 int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
 
@@ -121,7 +121,7 @@ int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
  * exit fired before the last Gaussian.
  *   state (4 x u32, out): state[0] = exit rank k* (GSX_RANK_NONE: no exit), state[1] = 1 if some
  *       pixel is unsaturated.  Ranks 0..k* are composited.
- *   chunk_state: max_chunks * (GSX_STATE_WORDS * 256 + 4) + 4 floats; with need_bwd = 1 it is left holding
+ *   chunk_state: GSX_CHUNK_STATE_FLOATS(max_chunks) floats; with need_bwd = 1 it is left holding
  *       what gsx_composite_bwd needs (per chunk and pixel: colour behind the chunk, transmittance
  *       at its end).
  *   rgb (3,H,W), alpha (H,W) accumulated alpha, depth_map (H,W) or NULL. */

@@ -45,9 +45,13 @@
  * floats): flags (bit 0 = every opacity staged for the chunk lies in [0, 1]; written by the chunk pass) and dark
  * bytes (byte w = 1 when every pixel of 8x8 quadrant w enters the chunk with |T| < 2^-GSX_CUT_LOG2; written by the
  * combine pass).  The backward masks a dark quadrant out only when the flag is set (then |T| cannot grow inside
- * the chunk).  Behind them: 4 u32 counters and two work lists of max_chunks chunk ids each (chunks with arithmetic
- * from the front, fully occluded chunks from the back; the second list is used after a global early exit). */
+ * the chunk).  Behind them: 16 u32 counters and 2 x 5 work lists of max_chunks chunk ids each (the backward's work
+ * items by expected cost, costliest first, fully occluded chunks last; the second set is used after a global
+ * early exit). */
 #define GSX_META_UNIT_OPACITY 1u
+#define GSX_META_COST_SHIFT 8     /* flags >> 8 = quadrant evaluations the forward counted for the chunk */
+/* floats the chunk-state buffer needs for max_chunks chunks (states, flags, dark bytes, work lists) */
+#define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + 12) + 16)
 
 /* "no saturation" marker for the per-pixel saturation rank */
 #define GSX_RANK_NONE 0xFFFFFFFFu
