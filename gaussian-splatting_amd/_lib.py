@@ -17,6 +17,7 @@ SYMBOLS = [
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd",
+    "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
@@ -68,6 +69,9 @@ def lib():
     L.gsx_clip_adam_workspace_bytes.restype = _sz
     L.gsx_clip_adam_step.argtypes = [_i32, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64, C.c_float,
                                      _i32, _p, _sz, _p]
+    L.gsx_keep_flags.argtypes = [_p, _i32, C.c_float, _p, _p]
+    L.gsx_compact_rows.argtypes = [_p, _p, _p, _i32, _i32, _p, _p]
+    L.gsx_clamp_inplace.argtypes = [_p, _i64, C.c_float, C.c_float, _p]
     L.gsx_image_loss_workspace_bytes.restype = _sz
     L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
     L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]

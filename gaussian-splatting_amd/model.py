@@ -84,6 +84,125 @@ class GaussianSplat(nn.Module):
         `model(pose.unsqueeze(0), size)['rendered_images'][0]` (utils/visualization.py:343-347), in one call."""
         return render_orbit(self.positions, self.scales, self.rotations, self.opacity, self.features, camera_poses, image_size)
 
+    # ---- maintenance of the parameter buffers (SURVEY 8f row N3; gaussian_splatting.py:346-528).  None of the
+    # reference's scripts call these; they are here so that a user of the module finds the same methods.  On the
+    # GPU prune and clamp run as HIP passes (csrc/gsx_maint.hip); CPU tensors (host-side tooling) use torch ops.
+    def _replace_parameters(self, tensors):
+        for k, t in zip(("positions", "scales", "rotations", "opacity", "features"), tensors):
+            setattr(self, k, nn.Parameter(t))
+        self.num_gaussians = int(tensors[0].shape[0])
+
+    @torch.no_grad()
+    def prune_gaussians(self, threshold: float = 0.01) -> None:
+        """Removes the Gaussians whose opacity is not above `threshold` (:346-369); order of the rest is kept.
+        Like the reference this replaces the nn.Parameters (optimizers must be rebuilt)."""
+        params = [self.positions, self.scales, self.rotations, self.opacity, self.features]
+        if not self.opacity.is_cuda:
+            mask = self.opacity.squeeze(-1) > threshold
+            self._replace_parameters([p.data[mask] for p in params])
+            return
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        n = self.opacity.shape[0]; dev = self.opacity.device
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        wsb = lib.gsx_scan_workspace_bytes(max(n, 1)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        L.check(lib.gsx_keep_flags(ptr(self.opacity.data.contiguous()), n, float(threshold), ptr(keep), st), "gsx_keep_flags")
+        L.check(lib.gsx_scan_u32(ptr(keep), ptr(offsets), ptr(total), n, ptr(ws), wsb, st), "gsx_scan_u32")
+        kept = int(total.item())
+        out = []
+        for p in params:
+            src = p.data.contiguous().float()
+            row = src.numel() // max(n, 1)
+            dst = torch.empty((kept,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+            if kept:
+                L.check(lib.gsx_compact_rows(ptr(src), ptr(keep), ptr(offsets), n, row, ptr(dst), st), "gsx_compact_rows")
+            out.append(dst)
+        self._replace_parameters(out)
+
+    def add_gaussians(self, num_new: int) -> None:
+        """Appends `num_new` Gaussians initialised like the reference (:371-402): positions ~ N(0,1), unit scales,
+        identity rotations, zero opacity, colours ~ U(0,1) -- same draws in the same order on the parameters' device."""
+        dev = self.positions.device
+        new_positions = torch.randn(num_new, 3, device=dev)
+        new_scales = torch.ones(num_new, 3, device=dev)
+        new_rotations = torch.zeros(num_new, 4, device=dev)
+        new_opacity = torch.zeros(num_new, 1, device=dev)
+        new_features = torch.rand(num_new, 3, device=dev)
+        new_rotations[:, 0] = 1
+        with torch.no_grad():
+            self._replace_parameters([torch.cat([self.positions.data, new_positions]), torch.cat([self.scales.data, new_scales]),
+                                      torch.cat([self.rotations.data, new_rotations]), torch.cat([self.opacity.data, new_opacity]),
+                                      torch.cat([self.features.data, new_features])])
+
+    @torch.no_grad()
+    def optimize_scales(self) -> None:
+        """Clamps the scales to [1e-4, 1.0] (:404-418), in place."""
+        if not self.scales.is_cuda:
+            self.scales.data = torch.minimum(torch.maximum(self.scales.data, torch.tensor(0.0001)), torch.tensor(1.0))
+            return
+        import ctypes as C
+        from . import _lib as L
+        s = self.scales.data
+        if not s.is_contiguous():
+            s = s.contiguous(); self.scales.data = s
+        L.check(L.lib().gsx_clamp_inplace(C.c_void_p(s.data_ptr()), s.numel(), 0.0001, 1.0,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsx_clamp_inplace")
+
+    @torch.no_grad()
+    def get_dense_points(self, num_points: int = 1000000) -> torch.Tensor:
+        """(num_points, 6) xyz+rgb samples, Gaussians drawn with probability softmax(opacity) (:420-443)."""
+        weights = F.softmax(self.opacity.squeeze(-1), dim=0)
+        indices = torch.multinomial(weights, num_points, replacement=True)
+        return torch.cat([self.positions[indices], self.features[indices]], dim=1)
+
+    def save_state(self, path: str) -> None:
+        """Same file layout as the reference (:445-461): a dict of num_gaussians and the five tensors."""
+        torch.save({'num_gaussians': self.num_gaussians, 'positions': self.positions.data, 'scales': self.scales.data,
+                    'rotations': self.rotations.data, 'opacity': self.opacity.data, 'features': self.features.data}, path)
+
+    def load_state(self, path: str) -> None:
+        """:463-476.  Loaded with weights_only=True (tensors and an int: nothing in the file is executed)."""
+        state = torch.load(path, weights_only=True)
+        self._replace_parameters([state[k] for k in ("positions", "scales", "rotations", "opacity", "features")])
+        self.num_gaussians = state['num_gaussians']
+
+    @torch.no_grad()
+    def merge_nearby_gaussians(self, distance_threshold: float = 0.01) -> None:
+        """Greedy merge of pairs closer than the threshold (:478-528): pairs (i < j) in row-major order, a Gaussian
+        takes part in at most one merge as the removed one, the survivor gets the opacity-weighted mean of position
+        and colour (of the CURRENT values, as in the reference) and the larger opacity.  The reference materialises
+        the N x N distance matrix; here it is scanned in row blocks, so N is bounded by time, not memory."""
+        n = self.num_gaussians
+        pos0 = self.positions.data
+        pairs = []
+        block = max(1, min(n, (1 << 24) // max(n, 1)))
+        for i0 in range(0, n, block):
+            d = torch.cdist(pos0[i0:i0 + block], pos0)
+            ii, jj = torch.where((d > 0) & (d < distance_threshold))
+            ii = ii + i0
+            sel = jj >= ii         # torch.triu keeps the diagonal: a self-distance that rounds above 0 "merges" i with itself (and removes it), as in the reference
+            pairs.append(torch.stack([ii[sel], jj[sel]], 1).cpu())
+        pairs = torch.cat(pairs) if pairs else torch.zeros(0, 2, dtype=torch.long)
+        merged = set()
+        for i, j in pairs.tolist():
+            if i in merged or j in merged:
+                continue
+            w1, w2 = self.opacity.data[i], self.opacity.data[j]
+            total_weight = w1 + w2
+            self.positions.data[i] = (w1 * self.positions.data[i] + w2 * self.positions.data[j]) / total_weight
+            self.features.data[i] = (w1 * self.features.data[i] + w2 * self.features.data[j]) / total_weight
+            self.opacity.data[i] = torch.maximum(w1, w2)
+            merged.add(j)
+        if merged:
+            keep = torch.ones(n, dtype=torch.bool, device=pos0.device)
+            keep[list(merged)] = False
+            self._replace_parameters([p.data[keep] for p in (self.positions, self.scales, self.rotations, self.opacity, self.features)])
+
     def last_n_composited(self):
         """Number of Gaussians composited before the global early exit (:147) in the last
         forward, per view (synchronises)."""

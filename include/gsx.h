@@ -185,6 +185,15 @@ int gsx_image_loss_fwd(int32_t kind, const float* pred, const float* target, int
 int gsx_image_loss_bwd(int32_t kind, const float* pred, const float* target, int64_t n,
                        const float* upstream, float* d_pred, void* stream);
 
+/* ---- maintenance of the parameter buffers (model/gaussian_splatting.py:346-369, :404-418).
+ * prune_gaussians = gsx_keep_flags (keep[i] = opacity[i] > threshold) -> gsx_scan_u32 (offsets, kept count) ->
+ * gsx_compact_rows once per parameter tensor (order-preserving: dst[offsets[i]] = src[i] for kept rows of
+ * row_floats floats; dst needs kept-count rows).  optimize_scales = gsx_clamp_inplace(scales, 3N, 1e-4, 1.0). */
+int gsx_keep_flags(const float* opacity, int32_t N, float threshold, uint32_t* keep, void* stream);
+int gsx_compact_rows(const float* src, const uint32_t* keep, const uint32_t* offsets, int32_t N, int32_t row_floats,
+                     float* dst, void* stream);
+int gsx_clamp_inplace(float* x, int64_t n, float lo, float hi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

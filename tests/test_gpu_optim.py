@@ -124,3 +124,34 @@ def test_trainer_three_steps_match_reference(fused):
             lr = DEFAULT_LRS[k]
             assert np.quantile(d, 0.99) <= 0.02 * lr, (s, k, float(np.quantile(d, 0.99)), lr)
             assert d.max() <= (s + 1) * lr * 1.01, (s, k, float(d.max()))
+
+
+def test_maintenance_kernels_match_cpu():
+    """SURVEY 8f N3 on the GPU (gsx_keep_flags + gsx_scan_u32 + gsx_compact_rows, gsx_clamp_inplace) against the same
+    module methods on CPU tensors (torch ops restating gaussian_splatting.py:346-369, :404-418): bit-equal, order kept,
+    NaN handled like torch (NaN opacity is pruned, NaN scale stays NaN)."""
+    from gaussian_splatting_amd import GaussianSplat
+    dev = torch.device("cuda:0")
+    for n in (1, 257, 100_003):
+        torch.manual_seed(n)
+        a = GaussianSplat(n)
+        with torch.no_grad():
+            a.scales.data[::5] = 3.0; a.scales.data[1::7] = 1e-6
+            if n > 10:
+                a.scales.data[3, 1] = float("nan"); a.opacity.data[5] = float("nan")
+        b = GaussianSplat(n)
+        b.load_state_dict(a.state_dict())
+        b = b.to(dev)
+        a.optimize_scales(); b.optimize_scales()
+        assert torch.equal(a.scales.data, b.scales.data.cpu(), ) or (torch.isnan(a.scales.data) == torch.isnan(b.scales.data.cpu())).all()
+        sa, sb = a.scales.data, b.scales.data.cpu()
+        ok = ~torch.isnan(sa)
+        assert torch.equal(sa[ok], sb[ok]) and torch.equal(torch.isnan(sa), torch.isnan(sb))
+        for thr in (0.5, -1.0, 2.0):
+            a2 = GaussianSplat(n); a2.load_state_dict(a.state_dict())
+            b2 = GaussianSplat(n); b2.load_state_dict(a.state_dict()); b2 = b2.to(dev)
+            a2.prune_gaussians(thr); b2.prune_gaussians(thr)
+            assert a2.num_gaussians == b2.num_gaussians
+            for k in ("positions", "rotations", "opacity", "features"):
+                x, y = getattr(a2, k).data, getattr(b2, k).data.cpu()
+                assert x.shape == y.shape and torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), (n, thr, k)

@@ -171,3 +171,69 @@ def test_data_parallel_gradient_path_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+def _maint_module(n, seed):
+    import torch
+    from gaussian_splatting_amd import GaussianSplat
+    torch.manual_seed(seed)
+    m = GaussianSplat(n)
+    with torch.no_grad():
+        m.scales.data[::5] = 3.0; m.scales.data[1::7] = 1e-6
+    return m
+
+
+def test_maintenance_methods_follow_reference_semantics():
+    """SURVEY 8f N3 (gaussian_splatting.py:346-528) on CPU tensors: prune (opacity > threshold, order kept, Parameters
+    replaced), add (init values, count), optimize_scales (clamp to [1e-4, 1]), dense points, save/load, greedy merge
+    against a dense N x N restatement of the reference loop."""
+    import torch
+    m = _maint_module(300, 3)
+    before = {k: getattr(m, k).data.clone() for k in ("positions", "scales", "rotations", "opacity", "features")}
+    mask = before["opacity"].squeeze() > 0.4
+    m.prune_gaussians(0.4)
+    assert m.num_gaussians == int(mask.sum())
+    for k, v in before.items():
+        assert torch.equal(getattr(m, k).data, v[mask]) and isinstance(getattr(m, k), torch.nn.Parameter)
+    n0 = m.num_gaussians
+    m.add_gaussians(11)
+    assert m.num_gaussians == n0 + 11 and m.rotations.shape == (n0 + 11, 4)
+    assert torch.equal(m.rotations.data[n0:], torch.tensor([[1., 0, 0, 0]]).expand(11, 4))
+    assert torch.all(m.opacity.data[n0:] == 0) and torch.all(m.scales.data[n0:] == 1)
+    s = m.scales.data.clone()
+    m.optimize_scales()
+    assert torch.equal(m.scales.data, s.clamp(0.0001, 1.0))
+    pts = m.get_dense_points(1000)
+    assert pts.shape == (1000, 6)
+    # greedy merge vs the reference's dense formulation
+    m = _maint_module(200, 4)
+    with torch.no_grad():
+        m.positions.data[50:100] = m.positions.data[0:50] + 0.002 * torch.randn(50, 3)     # 50 close pairs (+ chance triples)
+        m.positions.data[100:120] = m.positions.data[0:20] + 0.002 * torch.randn(20, 3)
+    P, Fe, Op = m.positions.data.clone(), m.features.data.clone(), m.opacity.data.clone()
+    d = torch.cdist(P, P)
+    ii, jj = torch.where(torch.triu(d > 0) & torch.triu(d < 0.01))
+    merged = set()
+    for i, j in zip(ii.tolist(), jj.tolist()):
+        if i in merged or j in merged:
+            continue
+        w1, w2 = Op[i].clone(), Op[j].clone()
+        P[i] = (w1 * P[i] + w2 * P[j]) / (w1 + w2); Fe[i] = (w1 * Fe[i] + w2 * Fe[j]) / (w1 + w2); Op[i] = torch.maximum(w1, w2)
+        merged.add(j)
+    keep = torch.ones(200, dtype=torch.bool); keep[list(merged)] = False
+    m.merge_nearby_gaussians(0.01)
+    assert m.num_gaussians == int(keep.sum()) and len(merged) >= 50
+    assert torch.equal(m.positions.data, P[keep]) and torch.equal(m.features.data, Fe[keep]) and torch.equal(m.opacity.data, Op[keep])
+
+
+def test_save_load_state_roundtrip(tmp_path):
+    import torch
+    from gaussian_splatting_amd import GaussianSplat
+    m = _maint_module(40, 5)
+    path = str(tmp_path / "state.pt")
+    m.save_state(path)
+    st = torch.load(path, weights_only=True)
+    assert sorted(st.keys()) == sorted(["num_gaussians", "positions", "scales", "rotations", "opacity", "features"])   # :452-459
+    m2 = GaussianSplat(3)
+    m2.load_state(path)
+    assert m2.num_gaussians == 40 and torch.equal(m2.features.data, m.features.data)
