@@ -155,3 +155,26 @@ def test_maintenance_kernels_match_cpu():
             for k in ("positions", "rotations", "opacity", "features"):
                 x, y = getattr(a2, k).data, getattr(b2, k).data.cpu()
                 assert x.shape == y.shape and torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), (n, thr, k)
+
+
+def test_device_prefetcher_feeds_the_trainer_step(tmp_path):
+    """items staged through pinned memory on a side stream arrive intact and drive a trainer step."""
+    from test_host_cpu import _write_scene
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.dataset import SceneDataset, DevicePrefetcher
+    from gaussian_splatting_amd.trainer import make_optimizer, train_step, l1_loss
+    root = str(tmp_path / "scene")
+    _write_scene(root, n=4, H=32, W=48)
+    ds = SceneDataset(root, "train")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = GaussianSplat(500).to(dev)
+    opt = make_optimizer(m, fused_clip_norm=0.1)
+    seen = 0
+    for img, pose, path in DevicePrefetcher(ds, dev):
+        ref = ds[seen]
+        assert img.is_cuda and torch.equal(img[0].cpu(), ref["image"]) and torch.equal(pose[0].cpu(), ref["camera_pose"])
+        loss = train_step(m, opt, pose, img, l1_loss, 0.1)
+        assert torch.isfinite(loss)
+        seen += 1
+    assert seen == 4

@@ -237,3 +237,54 @@ def test_save_load_state_roundtrip(tmp_path):
     m2 = GaussianSplat(3)
     m2.load_state(path)
     assert m2.num_gaussians == 40 and torch.equal(m2.features.data, m.features.data)
+
+
+def _write_scene(root, n=5, H=12, W=16, split="train"):
+    """A tiny scene in the reference's on-disk layout (data_processing/preprocessor.py:177-220,262-293)."""
+    import json, os
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, "images", split)); os.makedirs(os.path.join(root, "poses")); os.makedirs(os.path.join(root, "metadata"))
+    imgs = []
+    for i in range(n):
+        a = (np.kron(rng.integers(0, 255, (H // 4, W // 4, 3)), np.ones((4, 4, 1)))).astype(np.uint8)    # blocky: survives JPEG
+        Image.fromarray(a).save(os.path.join(root, "images", split, f"{i:04d}.jpg"), quality=95)
+        imgs.append(a)
+    poses = np.tile(np.eye(4, dtype=np.float64), (n, 1, 1)); poses[:, :3, 3] = rng.standard_normal((n, 3))
+    np.save(os.path.join(root, "poses", f"{split}_poses.npy"), poses)
+    with open(os.path.join(root, "metadata", "scene_info.json"), "w") as f:
+        json.dump({"metadata": {"camera": {"focal_length": 20.0, "principal_point": [W / 2, H / 2]}}, "processing": {"image_size": [W, H]}}, f)
+    return imgs, poses
+
+
+def test_scene_dataset_follows_reference_format(tmp_path):
+    """SURVEY 8f N2 (data_processing/dataset.py:11-216): items, dtypes, ordering, helper methods and errors."""
+    import torch
+    from gaussian_splatting_amd.dataset import SceneDataset, DevicePrefetcher
+    root = str(tmp_path / "scene")
+    imgs, poses = _write_scene(root)
+    ds = SceneDataset(root, "train")
+    assert len(ds) == 5
+    it = ds[2]
+    assert set(it) == {"image", "camera_pose", "image_path"} and it["image_path"].endswith("0002.jpg")
+    assert it["image"].shape == (3, 12, 16) and it["image"].dtype == torch.float32
+    assert float(it["image"].min()) >= 0 and float(it["image"].max()) <= 1
+    from PIL import Image
+    decoded = np.asarray(Image.open(it["image_path"]).convert("RGB"), dtype=np.float32) / 255.0
+    assert np.array_equal(it["image"].permute(1, 2, 0).numpy(), decoded)                    # the file's RGB bytes / 255, CHW
+    assert np.abs(decoded * 255 - imgs[2]).mean() < 20                                      # and it is the image that was written (lossy JPEG)
+    assert it["camera_pose"].dtype == torch.float32 and np.allclose(it["camera_pose"].numpy(), poses[2].astype(np.float32))
+    assert SceneDataset(root, "train", image_size=(8, 6))[0]["image"].shape == (3, 6, 8)    # (W, H) like cv2.resize
+    assert ds.get_camera_intrinsics() == {"focal_length": 20.0, "principal_point": (8.0, 6.0), "image_size": (16, 12)}
+    b = ds.get_scene_bounds()
+    assert np.allclose(b["aabb"], np.stack([poses[:, :3, 3].min(0), poses[:, :3, 3].max(0)]))
+    with pytest.raises(ValueError):
+        SceneDataset(root, "holdout")
+    with pytest.raises(FileNotFoundError):
+        SceneDataset(root, "val")
+    np.save(str(tmp_path / "scene" / "poses" / "train_poses.npy"), poses[:3])
+    with pytest.raises(ValueError):
+        SceneDataset(root, "train")
+    np.save(str(tmp_path / "scene" / "poses" / "train_poses.npy"), poses)
+    got = list(DevicePrefetcher(SceneDataset(root, "train"), "cpu", order=[3, 0]))
+    assert len(got) == 2 and got[0][0].shape == (1, 3, 12, 16) and got[0][1].shape == (1, 4, 4) and got[1][2].endswith("0000.jpg")
