@@ -164,6 +164,12 @@ __device__ __forceinline__ float* state_ptr(float* chunk_state, uint32_t chunk, 
     return chunk_state + ((size_t)chunk * GSX_STATE_WORDS + word) * kPixPerTile + pix;
 }
 
+__global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ work)
+{
+    if (threadIdx.x < 4) state[threadIdx.x] = 0u;
+    if (threadIdx.x < 16) work[threadIdx.x] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // F1: one wave per chunk, local compositing from (C = 0, T = 1)
 // ------------------------------------------------------------------------------------------
@@ -661,9 +667,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     const float4* r4 = (const float4*)rec;
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
-    GSX_HIP(hipMemsetAsync(state, 0, 16, st));
     uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
-    GSX_HIP(hipMemsetAsync(work, 0, 64, st));
+    clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // one launch instead of two memsets
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);

@@ -2,7 +2,7 @@
 // splat model: the step right after the gradient all-reduce in the reference's trainer
 // (/root/reference/training/trainer.py:169-175: torch.nn.utils.clip_grad_norm_(params, 0.1) then
 // torch.optim.Adam.step() with five per-tensor learning rates, :49-61).  SURVEY 8f row N4.
-// Three launches instead of ~25 foreach kernels; HBM-bound: 4 B read for the norm + 28 B
+// Two launches instead of ~25 foreach kernels; HBM-bound: 4 B read for the norm + 28 B
 // read/written per element for the update.  Arithmetic follows torch's foreach Adam operation by
 // operation (lerp, mul+addcmul, sqrt/div/add, addcdiv); compiled with -ffp-contract=off.
 #include "gsx_common.h"
@@ -64,8 +64,10 @@ __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __res
     if (threadIdx.x == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-// out[0] = total_norm, out[1] = clip coefficient = min(1, max_norm / (total_norm + 1e-6))
-__global__ __launch_bounds__(kBlock) void clip_coef_kernel(const double* __restrict__ partials, float max_norm, float* __restrict__ out)
+// total_norm and clip coefficient = min(1, max_norm / (total_norm + 1e-6)) from the kNormBlocks partial sums.  Every
+// workgroup of the update kernel runs it itself (same values, same order -> the same bits everywhere): 8 KB of
+// L2 reads per workgroup instead of a separate one-workgroup launch between the two passes.
+__device__ __forceinline__ float clip_coefficient(const double* __restrict__ partials, float max_norm, float* norm_out)
 {
     __shared__ double s_v[kBlock];
     double s = 0.0;
@@ -73,12 +75,10 @@ __global__ __launch_bounds__(kBlock) void clip_coef_kernel(const double* __restr
     s_v[threadIdx.x] = s;
     __syncthreads();
     for (int d = kBlock / 2; d > 0; d >>= 1) { if (threadIdx.x < d) s_v[threadIdx.x] += s_v[threadIdx.x + d]; __syncthreads(); }
-    if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(s_v[0]);
-        float coef = max_norm / (norm + 1e-6f);
-        out[0] = norm;
-        out[1] = coef < 1.0f ? coef : 1.0f;
-    }
+    const float norm = (float)sqrt(s_v[0]);
+    const float coef = max_norm / (norm + 1e-6f);
+    *norm_out = norm;
+    return coef < 1.0f ? coef : 1.0f;
 }
 
 __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, bool clip, float coef, float w1, float w2,
@@ -92,12 +92,18 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
     p = p + neg_step * (m / denom);          // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
-__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const float* __restrict__ coef_ptr, int write_clipped_grad,
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const double* __restrict__ partials, float max_norm,
+                                                      float* __restrict__ norm_coef_out, int write_clipped_grad,
                                                       float beta1, float beta2, float eps, float bc2_sqrt)
 {
     const long long total = a.qbegin[a.n_tensors];
-    const bool clip = coef_ptr != nullptr;
-    const float coef = clip ? coef_ptr[1] : 1.0f;
+    const bool clip = partials != nullptr;
+    float coef = 1.0f;
+    if (clip) {
+        float norm;
+        coef = clip_coefficient(partials, max_norm, &norm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { norm_coef_out[0] = norm; norm_coef_out[1] = coef; }
+    }
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
     for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < total; q += (long long)gridDim.x * kBlock) {
         const int t = find_tensor_q(a, q);
@@ -156,16 +162,16 @@ GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, flo
     const long long total = a.begin[n_tensors];
     if (total == 0) return GSX_OK;
     hipStream_t st = (hipStream_t)stream;
-    float* coef = nullptr;
+    double* partials = nullptr;
+    float* norm_coef = nullptr;
     if (max_grad_norm > 0.0f) {
-        double* partials = (double*)ws;
-        coef = (float*)((char*)ws + (size_t)kNormBlocks * 8);
+        partials = (double*)ws;
+        norm_coef = (float*)((char*)ws + (size_t)kNormBlocks * 8);
         sumsq_kernel<<<dim3(kNormBlocks), dim3(kBlock), 0, st>>>(a, partials);
-        clip_coef_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(partials, max_grad_norm, coef);
     }
     const long long blocks = ceil_div(a.qbegin[n_tensors], kBlock);
-    adam_kernel<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, st>>>(
-        a, coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
+    adam_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0, st>>>(
+        a, partials, max_grad_norm, norm_coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
