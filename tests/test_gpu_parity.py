@@ -92,7 +92,7 @@ def assert_integer_products_equal(gp, fw):
 # building blocks
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 63, 256, 4096, 4097, 70001, 1 << 20])
-@pytest.mark.parametrize("bits", [(0, 32), (0, 12), (4, 9), (0, 1)])
+@pytest.mark.parametrize("bits", [(0, 32), (0, 12), (4, 9), (0, 1), (0, 25), (3, 32), (0, 24)])
 def test_radix_sort_stable(dev, n, bits):
     import ctypes as C
     from gaussian_splatting_amd import _lib as L
