@@ -41,7 +41,7 @@ for v in views:
     dark = (mx < 2.0 ** -24).cpu().numpy()
     tiles = np.nonzero(lens)[0]
     res2 = {}
-    for name, bounds in {"4,16": (4, 16), "8,24": (8, 24), "2,6,14,30": (2, 6, 14, 30), "4,12,28": (4, 12, 28), "8": (8,), "16": (16,)}.items():
+    for name, bounds in {"4,16": (4, 16), "8,24": (8, 24), "2,6,14,30": (2, 6, 14, 30), "4,12,28": (4, 12, 28), "8": (8,), "16": (16,), "20": (20,), "24": (24,), "28": (28,), "32": (32,), "16,32": (16, 32), "12,24": (12, 24)}.items():
         sk = 0
         for t in tiles:
             c0, c1 = cb[t], cb[t + 1]; nc = c1 - c0
