@@ -15,7 +15,7 @@ poses = torch.from_numpy(create_orbit_poses(4.0, 60, 45.0)).to(dev)
 for v in views:
     outs, vs, extra = R.forward_view(P, poses[v], H, W)
     torch.cuda.synchronize()
-    cb = vs.chunk_base.cpu().numpy().astype(np.int64)
+    cb = vs.chunk_base.cpu().numpy().astype(np.int64)[: vs.ranges.shape[0] + 1]
     nch = int(cb[-1])
     st = vs.chunk_state[: nch * 8 * 256].view(nch, 8, 256)
     T_end = torch.ldexp(st[:, 6, :], st[:, 7, :].view(torch.int32))          # (nch, 256)
