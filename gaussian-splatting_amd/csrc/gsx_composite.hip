@@ -199,7 +199,10 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
     bool stop = false;
     uint32_t active = 0;
-    bool unit_opacity = true;                 // every staged opacity in [0, 1] (so |T| cannot grow inside the chunk)
+    // Bound on how much |T| can GROW inside the chunk, in bits: alpha = o * G with G in (0, 1], so |1 - alpha| <= 1 for
+    // o in [0, 2], <= 1 - o for o < 0 and <= o - 1 for o > 2; the sum of log2 of those factors over the chunk's splats
+    // bounds log2(|T_k| / |T_start|) for every k.  Zero for ordinary opacities.
+    float growth = 0.0f;
     uint32_t cost = 0;                        // quadrant evaluations of this chunk (the backward's cost estimate)
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
             const float4 a = R[0], b = R[1];
-            unit_opacity = unit_opacity && (b.y >= 0.0f) && (b.y <= 1.0f);
+            if (!(b.y >= 0.0f && b.y <= 2.0f)) growth += __builtin_amdgcn_logf(fabsf(b.y - 1.0f)) + 1e-3f;     // NaN stays NaN
             float4 c = R[2];
             c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
@@ -251,8 +254,11 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         *state_ptr(chunk_state, chunk, 4, pix) = __int_as_float(e[k]);
         *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
     }
-    const bool all_unit = __builtin_amdgcn_ballot_w64(!unit_opacity) == 0ull;
-    if (lane == 0) chunk_meta[chunk] = (all_unit ? GSX_META_UNIT_OPACITY : 0u) | (cost << GSX_META_COST_SHIFT);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) growth += __shfl_xor(growth, d, 64);
+    // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
+    const uint32_t gbits = (growth == 0.0f) ? 0u : (growth < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)growth + 2u : (uint32_t)GSX_META_GROWTH_MAX;
+    if (lane == 0) chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,9 +302,11 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             if (c < c1) {
                 if (need_bwd) {
                     // occlusion cut: byte w of chunk_dark[c] = 1 when every pixel of quadrant w (this wave's 64 pixels)
-                    // enters chunk c with |T| < 2^-GSX_CUT_LOG2 (|m| < 1 after renorm, so e <= -24 suffices); pixels
-                    // outside the image carry no gradient and count as dark
-                    const bool darkp = !inside || m == 0.0f || e <= -GSX_CUT_LOG2;
+                    // enters chunk c with |T| < 2^-(GSX_CUT_LOG2 + growth bits of c) (|m| < 1 after renorm, so a test
+                    // on e suffices): then |T| stays below 2^-24 throughout the chunk.  Pixels outside the image carry
+                    // no gradient and count as dark
+                    const uint32_t gb = chunk_meta[c] >> GSX_META_GROWTH_SHIFT;          // bits |T| may grow inside chunk c
+                    const bool darkp = gb < GSX_META_GROWTH_MAX && (!inside || m == 0.0f || e <= -GSX_CUT_LOG2 - (int)gb);
                     const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
                     if ((threadIdx.x & 63) == 0) {
                         reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = all_dark ? 1 : 0;
@@ -325,9 +333,8 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                 int cls = -1;
                 if (valid) {
                     const uint32_t meta = chunk_meta[c];
-                    const uint32_t n_dark = (meta & GSX_META_UNIT_OPACITY)
-                        ? (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]) : 0u;
-                    const uint32_t est = (meta >> GSX_META_COST_SHIFT) * (4u - n_dark);      // <= 4 * 4 * GSX_CHUNK
+                    const uint32_t n_dark = (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]);
+                    const uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * GSX_CHUNK
                     cls = n_dark == 4u ? 4 : est >= 10u * GSX_CHUNK ? 0 : est >= 6u * GSX_CHUNK ? 1 : est >= 3u * GSX_CHUNK ? 2 : 3;
                 }
                 const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
@@ -528,16 +535,13 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     if (eff_end == g.begin) return;
     const int lane = threadIdx.x;
     // Occlusion cut (the transmittance twin of the footprint cut): if every pixel of a quadrant enters this chunk
-    // with |T| < 2^-GSX_CUT_LOG2 and no opacity in the chunk lies outside [0, 1] (so |T| cannot grow inside it),
+    // with |T| < 2^-(GSX_CUT_LOG2 + g), g = the chunk's bound on the growth of |T| in bits (0 unless an opacity lies outside [0, 2]),
     // every weight T*alpha there is below 2^-24 and so is every dL/dalpha per unit of upstream gradient: the
     // quadrant is masked out for the whole chunk, and a chunk with four dark quadrants writes its rows as zeros
     // without evaluating a pair.  Half of a dense view's chunks go this way.
-    // chunk_dark[chunk]: one byte per 8x8 quadrant, written by the combine pass; only trusted for unit-opacity chunks
-    uint32_t dark_mask = 0;
-    if (chunk_meta[chunk] & GSX_META_UNIT_OPACITY) {
-        const uint32_t dw = chunk_dark[chunk];
-        dark_mask = (dw & 1u) | ((dw >> 7) & 2u) | ((dw >> 14) & 4u) | ((dw >> 21) & 8u);
-    }
+    // chunk_dark[chunk]: one byte per 8x8 quadrant, written by the combine pass (growth bound included)
+    const uint32_t dw = chunk_dark[chunk];
+    const uint32_t dark_mask = (dw & 1u) | ((dw >> 7) & 2u) | ((dw >> 14) & 4u) | ((dw >> 21) & 8u);
     {
         if (dark_mask == 0xFu) {
             for (uint32_t i = g.begin + lane; i < eff_end; i += 64) {
@@ -725,4 +729,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 7; }
+GSX_API int gsx_abi_version(void) { return 8; }

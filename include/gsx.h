@@ -136,7 +136,7 @@ int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint
  * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
  * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
  * Occlusion cut: an 8x8 quadrant that all its pixels enter a chunk with |T| < 2^-GSX_CUT_LOG2 is masked out for
- * that chunk if the chunk's opacities all lie in [0, 1] (all its weights T*alpha are below 2^-24, like the pairs
+ * that chunk with the chunk's growth bound included (gsx_constants.h), so that all its weights T*alpha stay below 2^-23, like the pairs
  * the footprint cut drops); a chunk with four dark quadrants gets zero rows without evaluating a pair.
  *   partials: >= D rows of 9 floats. */
 int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,

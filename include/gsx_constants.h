@@ -42,14 +42,17 @@
  *  5 local depth  6,7 transmittance at the chunk's end (mantissa, exponent) */
 #define GSX_STATE_WORDS 8
 /* the chunk-state buffer ends with two u32 arrays of max_chunks entries (after max_chunks * GSX_STATE_WORDS * 256
- * floats): flags (bit 0 = every opacity staged for the chunk lies in [0, 1]; written by the chunk pass) and dark
- * bytes (byte w = 1 when every pixel of 8x8 quadrant w enters the chunk with |T| < 2^-GSX_CUT_LOG2; written by the
- * combine pass).  The backward masks a dark quadrant out only when the flag is set (then |T| cannot grow inside
- * the chunk).  Behind them: 16 u32 counters and 2 x 5 work lists of max_chunks chunk ids each (the backward's work
- * items by expected cost, costliest first, fully occluded chunks last; the second set is used after a global
- * early exit). */
-#define GSX_META_UNIT_OPACITY 1u
-#define GSX_META_COST_SHIFT 8     /* flags >> 8 = quadrant evaluations the forward counted for the chunk */
+ * floats).  flags (written by the chunk pass): bits 8..23 = quadrant evaluations the forward counted for the chunk
+ * (the backward's cost estimate), bits 24..31 = g, a bound in bits on the growth of |T| inside the chunk
+ * (alpha = o * G, G <= 1: |1 - alpha| <= 1 for o in [0, 2], so g = 0 for ordinary opacities; GSX_META_GROWTH_MAX =
+ * unbounded).  dark bytes (written by the combine pass): byte w = 1 when every pixel of 8x8 quadrant w enters the
+ * chunk with |T| < 2^-(GSX_CUT_LOG2 + g) -- the backward masks such a quadrant out.  Behind them: 16 u32 counters
+ * and 2 x 5 work lists of max_chunks chunk ids each (the backward's work items by expected cost, costliest first,
+ * fully occluded chunks last; the second set is used after a global early exit). */
+#define GSX_META_COST_SHIFT 8
+#define GSX_META_COST_MASK 0xFFFFu
+#define GSX_META_GROWTH_SHIFT 24
+#define GSX_META_GROWTH_MAX 255
 /* floats the chunk-state buffer needs for max_chunks chunks (states, flags, dark bytes, work lists) */
 #define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + 12) + 16)
 

@@ -304,8 +304,10 @@ def test_occlusion_cut_backward(dev, O):
     go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
     for k in PARAMS:
         assert rel_err(g[k], go[k]) < GRAD_RTOL, k
-    # out-of-range opacities switch the cut off for their chunks (|T| may grow inside them): still within tolerance
+    # opacities in (1, 2] keep |1 - alpha| <= 1; negative ones let |T| grow inside a chunk, which raises the chunk's
+    # darkness threshold by the growth bound (gsx_constants.h): still within tolerance
     params["opacity"][::7] = 1.5
+    params["opacity"][3::11] = -0.05
     gp = gpu_pipeline(params, pose, H, W, dev)
     fw = O.forward(params, pose, H, W, "tiled")
     g = gpu_backward(gp, H, W, d_rgb)

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsx.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.gsx_abi_version() == 7
+    assert lib.gsx_abi_version() == 8
     assert lib.gsx_strerror(-2).decode().startswith("instance buffers")
     # pure host helpers (no GPU): workspace sizes and the chunk bound
     assert lib.gsx_sort_workspace_bytes(1 << 20) >= 256 * 256 * 4
