@@ -12,24 +12,46 @@ int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t,
 size_t sort_ws_bytes_internal(int64_t n);
 
 // one thread per rank: write its tiles row-major at offsets[r]..  Writes stop at `capacity` (the caller finds
-// out that the buffers were too small when it reads the instance count, and retries).
+// out that the buffers were too small when it reads the instance count, and retries).  A splat that covers more than
+// kEmitSolo tiles is written by its whole wavefront (lane l takes tiles l, l+64, ...): one screen-sized splat would
+// otherwise keep a single lane busy for thousands of iterations while the rest of the chip waits.
+constexpr int kEmitSolo = 32;
 __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ offsets, int N, int tw,
                                                       uint32_t capacity, uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= N) return;
-    const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
-    const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
-    const int xlo = bx & 0xffff, xhi = bx >> 16, ylo = by & 0xffff, yhi = by >> 16;
-    if (xlo > xhi) return;
-    const int x0 = xlo >> GSX_TILE_SHIFT, x1 = (xhi >> GSX_TILE_SHIFT) + 1;
-    const int y0 = ylo >> GSX_TILE_SHIFT, y1 = (yhi >> GSX_TILE_SHIFT) + 1;
-    uint32_t o = offsets[r];
-    for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
-            if (o >= capacity) return;
-            tiles[o] = (uint32_t)(ty * tw + tx); ranks[o] = (uint32_t)r; o++;
+    const int lane = threadIdx.x & 63;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0; uint32_t o = 0;
+    if (r < N) {
+        const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
+        const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
+        const int xlo = bx & 0xffff, xhi = bx >> 16, ylo = by & 0xffff, yhi = by >> 16;
+        if (xlo <= xhi) {
+            x0 = xlo >> GSX_TILE_SHIFT; x1 = (xhi >> GSX_TILE_SHIFT) + 1;
+            y0 = ylo >> GSX_TILE_SHIFT; y1 = (yhi >> GSX_TILE_SHIFT) + 1;
+            o = offsets[r];
         }
+    }
+    const int cnt = (x1 - x0) * (y1 - y0);
+    if (cnt > 0 && cnt <= kEmitSolo) {
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) {
+                if (o >= capacity) break;
+                tiles[o] = (uint32_t)(ty * tw + tx); ranks[o] = (uint32_t)r; o++;
+            }
+    }
+    unsigned long long big = __ballot(cnt > kEmitSolo);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64), by0 = __shfl(y0, src, 64), bcnt = __shfl(cnt, src, 64);
+        const uint32_t bo = (uint32_t)__shfl((int)o, src, 64);
+        const int br = __shfl(r, src, 64), bw = bx1 - bx0;
+        for (int i = lane; i < bcnt; i += 64) {
+            const uint32_t dst = bo + (uint32_t)i;
+            if (dst < capacity) { tiles[dst] = (uint32_t)((by0 + i / bw) * tw + bx0 + i % bw); ranks[dst] = (uint32_t)br; }
+        }
+    }
 }
 
 // ranges[t] = [lower_bound(tiles, t), lower_bound(tiles, t+1))

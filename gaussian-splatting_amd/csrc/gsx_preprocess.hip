@@ -175,20 +175,46 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     int N, int accumulate,
     float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea)
 {
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= N) return;
-    const uint32_t r = rank_of[g];
+    const int g = blockIdx.x * kBlock + threadIdx.x;        // N is rounded up to whole waves below: no early return before the shuffles
+    const int lane = threadIdx.x & 63;
+    const bool live = g < N;
+    const uint32_t r = live ? rank_of[g] : 0u;
     float D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t limit = (uint32_t)N;
     if (state) { const uint32_t s = state[0]; if (s != GSX_RANK_NONE && s + 1u < (uint32_t)N) limit = s + 1u; }
-    if (partials && r < limit) {
-        const uint32_t o0 = offsets[r], tt = tiles_touched[r];
+    uint32_t o0 = 0, tt = 0;
+    if (live && partials && r < limit) { o0 = offsets[r]; tt = tiles_touched[r]; }
+    // rows of a splat: summed by its own lane in tile order when there are few; a splat with more than kRowsSolo rows
+    // is summed by the whole wavefront (lane l takes rows l, l+64, ... in order, then a fixed butterfly): a
+    // screen-sized splat would otherwise serialise thousands of loads in one lane.  Both orders are fixed, so the
+    // result stays bitwise reproducible.
+    constexpr uint32_t kRowsSolo = 32;
+    if (tt <= kRowsSolo) {
         for (uint32_t t = 0; t < tt; t++) {
             const float* row = partials + (size_t)9 * (o0 + t);
 #pragma unroll
             for (int c = 0; c < 9; c++) D[c] += row[c];
         }
     }
+    unsigned long long big = __ballot(tt > kRowsSolo);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t bo = (uint32_t)__shfl((int)o0, src, 64), bt = (uint32_t)__shfl((int)tt, src, 64);
+        float S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t t = (uint32_t)lane; t < bt; t += 64) {
+            const float* row = partials + (size_t)9 * (bo + t);
+#pragma unroll
+            for (int c = 0; c < 9; c++) S[c] += row[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) S[c] += __shfl_xor(S[c], d, 64);
+            if (lane == src) D[c] = S[c];
+        }
+    }
+    if (!live) return;
     float M[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) M[k] = pose[k];

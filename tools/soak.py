@@ -30,3 +30,12 @@ for w in range(K // 300):
     print(f"steps {w*300}-{w*300+299}: {(time.perf_counter()-t0)/300*1e3:.4f} ms/step, loss {losses[-1]:.6f}, "
           f"mean D {dsum // 10}, scale median {float(m.scales.data.median()):.5f}, peak mem {torch.cuda.max_memory_allocated()/2**20:.0f} MiB, reserved {torch.cuda.memory_reserved()/2**20:.0f} MiB", flush=True)
 assert all(np.isfinite(losses))
+# per-stage times on the evolved scene
+timer = R.StageTimer(); R.set_stage_timer(timer)
+for v in range(60):
+    opt.zero_grad()
+    out = m(poses[v:v + 1], (H, W))
+    l1_loss(out, target).backward()
+torch.cuda.synchronize(); R.set_stage_timer(None)
+print({k: round(t / c, 4) for k, (t, c) in timer.totals_ms().items()})
+print("opacity <0: %.3f, >1: %.3f, >2: %.3f" % (float((m.opacity < 0).float().mean()), float((m.opacity > 1).float().mean()), float((m.opacity > 2).float().mean())))
