@@ -375,3 +375,13 @@ def test_full_size_properties(dev):
     g3 = gpu_backward(gp, H, W, 2.0 * d_rgb)
     for k in PARAMS:
         assert rel_err(g3[k], 2.0 * g1[k]) < 1e-5
+    # the module (asynchronous binning, launches sized by capacity, autograd) gives the same bits as the staged pipeline
+    from gaussian_splatting_amd import GaussianSplat
+    m = GaussianSplat(n)
+    m.load_state_dict({k: torch.from_numpy(params[k]) for k in PARAMS})
+    m = m.to(dev)
+    out = m(torch.from_numpy(pose_tz(2.0)).to(dev)[None], (H, W))
+    assert np.array_equal(out["rendered_images"][0].detach().cpu().numpy(), gp["rgb"])
+    (out["rendered_images"][0] * torch.from_numpy(d_rgb).to(dev)).sum().backward()
+    for k in PARAMS:
+        assert np.array_equal(getattr(m, k).grad.cpu().numpy(), g1[k]), k
