@@ -115,7 +115,8 @@ int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
 /* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  A tile's depth-ordered
  * list is cut into chunks of GSX_CHUNK instances; one wave64 composites one chunk for the whole
  * 16x16 tile (4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
- * the chunks (compositing is associative) and writes the image.  Enqueues, in order: chunk pass,
+ * the chunks (compositing is associative), writes the image and -- with need_bwd -- each chunk's dark-quadrant
+ * bytes and the backward's work lists.  Enqueues, in order: chunk pass,
  * combine pass, exact early-exit search (only does work when every pixel saturated: the
  * reference's global exit, :147), and a second chunk + combine pass that only does work when the
  * exit fired before the last Gaussian.
@@ -135,9 +136,11 @@ int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint
  * per-splat partial sums over the wavefront (DPP) and stores ONE row per (tile, rank) instance at
  * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
  * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
- * Occlusion cut: an 8x8 quadrant that all its pixels enter a chunk with |T| < 2^-GSX_CUT_LOG2 is masked out for
- * that chunk with the chunk's growth bound included (gsx_constants.h), so that all its weights T*alpha stay below 2^-23, like the pairs
- * the footprint cut drops); a chunk with four dark quadrants gets zero rows without evaluating a pair.
+ * Occlusion cut: an 8x8 quadrant whose pixels all enter a chunk with |T| < 2^-(GSX_CUT_LOG2 + g), g = the chunk's
+ * bound on the growth of |T| in bits (gsx_constants.h; 0 unless an opacity lies outside [0, 2]), is masked out for
+ * that chunk: all its weights T*alpha stay below 2^-23, like the pairs the footprint cut drops.  A chunk with four
+ * dark quadrants gets zero rows without evaluating a pair.  gridDim = max_chunks: the chunks are taken from the
+ * work lists the forward's combine pass left in chunk_state (costliest first).
  *   partials: >= D rows of 9 floats. */
 int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
                       const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
