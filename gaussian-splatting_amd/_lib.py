@@ -17,6 +17,7 @@ SYMBOLS = [
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd",
+    "gsx_l1_ssim_workspace_bytes", "gsx_l1_ssim_fwd", "gsx_l1_ssim_bwd",
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
@@ -57,10 +58,10 @@ def lib():
     L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _sz, _p]
     L.gsx_scan_workspace_bytes.restype = _sz; L.gsx_scan_workspace_bytes.argtypes = [_i64]
     L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
-    L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p]
+    L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p]
     L.gsx_bin_workspace_bytes.restype = _sz; L.gsx_bin_workspace_bytes.argtypes = [_i32, _i64]
     L.gsx_bin_instances.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p, _sz, _p]
-    L.gsx_bin_count.argtypes = [_p, _i32, _p, _p, _p, _p, _sz, _p]
+    L.gsx_bin_count.argtypes = [_p, _p, _i32, _p, _p, _p, _p, _sz, _p]
     L.gsx_bin_emit_sort.argtypes = [_p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
@@ -75,12 +76,25 @@ def lib():
     L.gsx_image_loss_workspace_bytes.restype = _sz
     L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
     L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]
+    L.gsx_l1_ssim_workspace_bytes.restype = _sz; L.gsx_l1_ssim_workspace_bytes.argtypes = [_i32, _i32, _i32]
+    L.gsx_l1_ssim_fwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p]
+    L.gsx_l1_ssim_bwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p, _p]
     for name in SYMBOLS:
         getattr(L, name)
         if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name != "gsx_max_chunks":
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def stream_ptr():
+    """torch's current HIP stream on the current device as a c_void_p (the raw-handle getters are ~20x cheaper than
+    torch.cuda.current_stream(), which a trainer step would otherwise call a dozen times)."""
+    import torch
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def check(status, where):

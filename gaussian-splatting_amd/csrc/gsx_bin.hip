@@ -8,7 +8,7 @@ namespace gsx {
 
 int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, const uint64_t*, int, int,
                         void*, size_t, hipStream_t);
-int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t);
+int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0);
 size_t sort_ws_bytes_internal(int64_t n);
 
 // one thread per rank: write its tiles row-major at offsets[r]..  Writes stop at `capacity` (the caller finds
@@ -102,13 +102,13 @@ GSX_API int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W)
     return D / GSX_CHUNK + (D < n_tiles ? D : n_tiles);
 }
 
-GSX_API int gsx_bin_count(const uint32_t* tiles_touched, int32_t N, uint32_t* offsets, uint64_t* total_dev,
+GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, int32_t N, uint32_t* offsets, uint64_t* total_dev,
                           int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream)
 {
     if (N < 0 || !total_dev) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (N > 0 && (!tiles_touched || !offsets || !ws || ws_bytes < gsx_scan_workspace_bytes(N))) return GSX_E_INVALID;
-    int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st);     // N == 0: total = 0
+    int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st, tt_block_sums, kBlock);     // N == 0: total = 0
     if (s != GSX_OK) return s;
     if (D_pinned_host) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 8, hipMemcpyDeviceToHost, st));
     return GSX_OK;
@@ -162,7 +162,7 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     if (!rec || !tiles_touched || !offsets) return GSX_E_INVALID;
     uint64_t* total_dev = (uint64_t*)ws;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
-    int s = gsx_bin_count(tiles_touched, N, offsets, total_dev, nullptr, sub_ws, sub_bytes, stream);
+    int s = gsx_bin_count(tiles_touched, nullptr, N, offsets, total_dev, nullptr, sub_ws, sub_bytes, stream);
     if (s != GSX_OK) return s;
     uint64_t D = 0;
     GSX_HIP(hipMemcpyAsync(&D, total_dev, 8, hipMemcpyDeviceToHost, st));

@@ -177,10 +177,14 @@ template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t N, int H, int W, int tw, float stepx, float stepy,
-    const uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta)
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_rank[kCBatch];
+    if (!PASS1 && blockIdx.x == 0) {          // the combine pass (next launch) counts in these; pass 0 itself reads neither
+        if (threadIdx.x < 4) state[threadIdx.x] = 0u;
+        if (threadIdx.x < 16) work[threadIdx.x] = 0u;
+    }
     const uint32_t n_chunks = chunk_base[n_tiles];
     if (blockIdx.x >= n_chunks) return;
     const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
@@ -672,22 +676,22 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
-    clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // one launch instead of two memsets
+    if (max_chunks <= 0) clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // otherwise block 0 of the chunk pass clears them
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
+        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
         tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
     } else {
-        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
+        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
         tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
     }
     saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
-            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
+            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
             tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
         } else {
-            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta);
+            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
             tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
         }
     }
@@ -729,4 +733,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 8; }
+GSX_API int gsx_abi_version(void) { return 9; }

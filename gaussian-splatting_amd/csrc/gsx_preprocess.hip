@@ -117,12 +117,25 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __rest
     P[2] = make_float4(features[3*i], features[3*i+1], features[3*i+2], 0.0f);
 }
 
+// tt_sums (nullable): per-workgroup sum of tiles_touched, so that the scan that follows is one launch (gsx_bin_count)
+__device__ __forceinline__ void block_sum_tiles(uint32_t tt, uint64_t* __restrict__ tt_sums)
+{
+    __shared__ uint32_t s_tt[kBlock / 64];
+    uint32_t s = tt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);          // <= 64 * (4096^2 tiles) would wrap: summed per wave in
+    if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = s;              // u32 only for images up to 8192 tiles (checked on the host)
+    __syncthreads();
+    if (threadIdx.x == 0) tt_sums[blockIdx.x] = ((uint64_t)s_tt[0] + s_tt[1]) + ((uint64_t)s_tt[2] + s_tt[3]);
+}
+
 __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
                                                                int N, int H, int W, float* __restrict__ rec,
-                                                               uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of)
+                                                               uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of,
+                                                               uint64_t* __restrict__ tt_sums)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= N) return;
+    if (r >= N) { if (tt_sums) block_sum_tiles(0u, tt_sums); return; }
     const uint32_t g = order[r];
     rank_of[g] = (uint32_t)r;
     const float4 p0 = pre[(size_t)3 * g], p1 = pre[(size_t)3 * g + 1], p2 = pre[(size_t)3 * g + 2];
@@ -159,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __r
     R[0] = make_float4(mu.x, mu.y, m[0] * GSX_NEG_HALF_LOG2E, (m[1] + m[2]) * GSX_NEG_HALF_LOG2E);
     R[1] = make_float4(m[3] * GSX_NEG_HALF_LOG2E, op, p2.x, p2.y);
     R[2] = make_float4(p2.z, p1.z, __uint_as_float(bx), __uint_as_float(by));
+    if (tt_sums) block_sum_tiles(tt, tt_sums);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,14 +347,16 @@ GSX_API int gsx_project_fwd(const float* positions, const float* scales, const f
 }
 
 GSX_API int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
-                              float* rec, uint32_t* tiles_touched, uint32_t* rank_of, void* stream)
+                              float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
     if (!pre || !order || !rec || !tiles_touched || !rank_of) return GSX_E_INVALID;
     if (((uintptr_t)rec | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
+    // the per-wave partial sums are u32: 64 splats x n_tiles must fit
+    if (tt_block_sums && (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE) > (int64_t)(0xFFFFFFFFu / 64u)) return GSX_E_RANGE;
     build_records_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of);
+        (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of, tt_block_sums);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -60,46 +60,33 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// single workgroup: exclusive scan of nb u64 block sums in place; total -> *total
-__global__ __launch_bounds__(kBlock) void scan_top_kernel(uint64_t* __restrict__ block_sums, int64_t nb, uint64_t* __restrict__ total)
-{
-    __shared__ uint64_t s_w[4];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t start = 0; start < nb; start += kBlock) {
-        int64_t i = start + threadIdx.x;
-        uint64_t v = (i < nb) ? block_sums[i] : 0, incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint64_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        uint64_t base = s_carry;
-        for (int w = 0; w < wave; w++) base += s_w[w];
-        if (i < nb) block_sums[i] = base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) s_carry = base + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total) *total = s_carry;
-}
-
+// Second (and last) level: workgroup b first adds up the sums of everything before its tile -- `ratio` entries of
+// `sums` per tile, b * ratio values read by 256 threads, i.e. O(nb^2 / 2) reads of a table that sits in L2 -- instead of a
+// third launch for the scan of the sums (a dependent launch costs ~4.6 us; at 1 M elements the table is 4 KB).  The
+// last workgroup also writes the grand total.
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
-                                                            const uint64_t* __restrict__ block_sums)
+                                                            const uint64_t* __restrict__ sums, int ratio, uint64_t* __restrict__ total)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_pre[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t acc = 0;
+    const int64_t before = (int64_t)blockIdx.x * ratio;
+    for (int64_t j = threadIdx.x; j < before; j += kBlock) acc += sums[j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if (lane == 0) s_pre[wave] = acc;
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;   // blocked layout
     uint32_t v[kScanItems]; uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; v[k] = (i < n) ? in[i] : 0u; s += v[k]; }
     uint32_t tot;
-    uint32_t ex = block_excl_scan_u32(s, s_wave, &tot) + (uint32_t)block_sums[blockIdx.x];
+    const uint32_t ex0 = block_excl_scan_u32(s, s_wave, &tot);          // barriers inside: s_pre is visible after it
+    const uint64_t pre = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+    uint32_t ex = ex0 + (uint32_t)pre;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = pre + (uint64_t)tot;
 }
 
 // one workgroup of 1024 threads scans up to kSmallScan values in a single launch (radix histograms of
@@ -135,19 +122,27 @@ __global__ __launch_bounds__(kSmallThreads) void scan_small_kernel(const uint32_
     if (threadIdx.x == 0 && total) *total = s_carry;
 }
 
-static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st)
+// block_sums (nullable): sums of consecutive groups of `sums_tile` elements that the producer of `in` already has
+// (build_records: one per 256 ranks); then the scan is ONE launch.
+static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st,
+                       const uint64_t* block_sums = nullptr, int sums_tile = 0)
 {
-    if (n <= kSmallScan) {
+    if (n <= kSmallScan && !block_sums) {
         scan_small_kernel<<<dim3(1), dim3(kSmallThreads), 0, st>>>(in, out, n, total_dev);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }
     int64_t nb = ceil_div(n, kScanTile);
+    if (block_sums) {
+        if (sums_tile <= 0 || kScanTile % sums_tile != 0) return GSX_E_INVALID;
+        scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, block_sums, kScanTile / sums_tile, total_dev);
+        GSX_LAUNCH_CHECK();
+        return GSX_OK;
+    }
     if (ws_bytes < (size_t)nb * 8) return GSX_E_CAPACITY;
     uint64_t* sums = (uint64_t*)ws;
     scan_reduce_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, n, sums);
-    scan_top_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(sums, nb, total_dev);
-    scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, sums);
+    scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, sums, 1, total_dev);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -314,13 +309,14 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
     return GSX_OK;
 }
 
-int scan_internal(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st)
+int scan_internal(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st,
+                  const uint64_t* block_sums, int sums_tile)
 {
     if (n <= 0) {
         if (total_dev) GSX_HIP(hipMemsetAsync(total_dev, 0, 8, st));
         return GSX_OK;
     }
-    return scan_launch(in, out, total_dev, n, ws, ws_bytes, st);
+    return scan_launch(in, out, total_dev, n, ws, ws_bytes, st, block_sums, sums_tile);
 }
 
 size_t sort_ws_bytes_internal(int64_t n) { return sort_ws_bytes(n); }
@@ -350,5 +346,5 @@ GSX_API int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* 
 {
     if (n < 0) return GSX_E_INVALID;
     if (n > 0 && (!in || !out_exclusive || !ws)) return GSX_E_INVALID;
-    return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream);
+    return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
 }

@@ -13,8 +13,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = L.stream_ptr
 
 
 class _ImageLoss(torch.autograd.Function):
@@ -51,3 +50,44 @@ def l1(pred, target):
 def clamped_mse(pred, target):
     """F.mse_loss(clamp(pred, 1e-8, 1 - 1e-8), target) -- loss.py:135-137"""
     return _ImageLoss.apply(pred, target, CLAMPED_MSE)
+
+
+class _L1Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, lambda_dssim):
+        if not pred.is_cuda:
+            raise RuntimeError("gaussian-splatting_amd.loss runs on an MI355X only (no CPU fallback); use torch ops on CPU tensors")
+        if pred.dim() < 2:
+            raise ValueError("l1_ssim needs (..., H, W) images")
+        lib = L.lib()
+        p = pred.detach().contiguous().float()
+        t = target.detach().expand_as(pred).contiguous().float()
+        H, W = int(p.shape[-2]), int(p.shape[-1])
+        planes = p.numel() // (H * W)
+        loss3 = torch.empty(3, dtype=torch.float32, device=p.device)
+        wsb = lib.gsx_l1_ssim_workspace_bytes(planes, H, W)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
+        L.check(lib.gsx_l1_ssim_fwd(_ptr(p), _ptr(t), planes, H, W, float(lambda_dssim), _ptr(loss3), _ptr(ws), wsb, _stream()), "gsx_l1_ssim_fwd")
+        ctx.lam = float(lambda_dssim)
+        ctx.save_for_backward(p, t, ws)
+        ctx.mark_non_differentiable(loss3)
+        return loss3[0], loss3
+
+    @staticmethod
+    def backward(ctx, g, _g3):
+        p, t, ws = ctx.saved_tensors
+        lib = L.lib()
+        H, W = int(p.shape[-2]), int(p.shape[-1])
+        planes = p.numel() // (H * W)
+        d = torch.empty_like(p)
+        g = g.detach().contiguous().float()
+        L.check(lib.gsx_l1_ssim_bwd(_ptr(p), _ptr(t), planes, H, W, ctx.lam, _ptr(g), _ptr(ws), ws.numel(), _ptr(d), _stream()), "gsx_l1_ssim_bwd")
+        return d, None, None
+
+
+def l1_ssim(pred, target, lambda_dssim=0.2, return_terms=False):
+    """(1 - lambda) * mean|pred - target| + lambda * (1 - SSIM(pred, target)); SSIM per plane with an 11x11 Gaussian window
+    (sigma 1.5, zero padding), i.e. BASELINE config 2's "L1/SSIM".  pred: (..., H, W).  With return_terms also the
+    detached tensor (loss, l1, ssim)."""
+    loss, terms = _L1Ssim.apply(pred, target, lambda_dssim)
+    return (loss, terms) if return_terms else loss

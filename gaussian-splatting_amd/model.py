@@ -105,7 +105,7 @@ class GaussianSplat(nn.Module):
         from . import _lib as L
         lib = L.lib()
         n = self.opacity.shape[0]; dev = self.opacity.device
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = L.stream_ptr()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
@@ -151,7 +151,7 @@ class GaussianSplat(nn.Module):
         if not s.is_contiguous():
             s = s.contiguous(); self.scales.data = s
         L.check(L.lib().gsx_clamp_inplace(C.c_void_p(s.data_ptr()), s.numel(), 0.0001, 1.0,
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsx_clamp_inplace")
+                                          L.stream_ptr()), "gsx_clamp_inplace")
 
     @torch.no_grad()
     def get_dense_points(self, num_points: int = 1000000) -> torch.Tensor:

@@ -60,7 +60,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         L.check(lib.gsx_clip_adam_step(k, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * k)(*ns), (C.c_float * k)(*lrs),
                                        b1, b2, self.param_groups[0]['eps'], step, self.max_grad_norm,
                                        1 if self.write_clipped_grad else 0, C.c_void_p(self._ws.data_ptr()), self._ws.numel(),
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsx_clip_adam_step")
+                                       L.stream_ptr()), "gsx_clip_adam_step")
         return loss
 
     def last_grad_norm(self):

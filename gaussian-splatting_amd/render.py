@@ -14,8 +14,7 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = L.stream_ptr
 
 
 def _f32c(t):
@@ -121,9 +120,11 @@ def build_records(pre, order, H, W):
     rec = torch.empty(n, L.REC_FLOATS, dtype=torch.float32, device=dev)
     tt = torch.empty(n, dtype=torch.int32, device=dev)
     rank_of = torch.empty(n, dtype=torch.int32, device=dev)
+    tt_sums = torch.empty((n + 255) // 256, dtype=torch.int64, device=dev)
     with _stage("build_records"):
-        L.check(lib.gsx_build_records(_ptr(pre), _ptr(order), n, H, W, _ptr(rec), _ptr(tt), _ptr(rank_of), _stream()),
+        L.check(lib.gsx_build_records(_ptr(pre), _ptr(order), n, H, W, _ptr(rec), _ptr(tt), _ptr(rank_of), _ptr(tt_sums), _stream()),
                 "gsx_build_records")
+    tt._gsx_block_sums = tt_sums               # travels with the tensor: bin_count(tt) then scans in one launch
     return rec, tt, rank_of
 
 
@@ -161,13 +162,14 @@ def bin_count(tt):
     -> offsets, total_dev (device u64[1]), (pinned, event): the count is valid after event.synchronize()."""
     lib = L.lib()
     n = tt.numel(); dev = tt.device
+    tt_sums = getattr(tt, "_gsx_block_sums", None)      # left by build_records on exactly this tensor, if any
     offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int64, device=dev)
     wsb = lib.gsx_scan_workspace_bytes(max(n, 1))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     pinned, ev = _scratch.count_slot(dev)
     with _stage("bin_count"):
-        L.check(lib.gsx_bin_count(_ptr(tt), n, _ptr(offsets), _ptr(total), C.c_void_p(pinned.data_ptr()), _ptr(ws), wsb, _stream()),
+        L.check(lib.gsx_bin_count(_ptr(tt), _ptr(tt_sums), n, _ptr(offsets), _ptr(total), C.c_void_p(pinned.data_ptr()), _ptr(ws), wsb, _stream()),
                 "gsx_bin_count")
     ev.record()
     return offsets, total, (pinned, ev)

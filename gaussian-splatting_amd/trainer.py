@@ -44,6 +44,15 @@ def l1_loss(outputs, target):
     return (c - target).abs().mean()
 
 
+def l1_ssim_loss(outputs, target, lambda_dssim=0.2):
+    """BASELINE config 2's criterion: (1 - lambda) L1 + lambda (1 - SSIM), fused in HIP on the GPU (loss.l1_ssim)."""
+    c = outputs['rendered_images']
+    if c.is_cuda:
+        from . import loss as _loss
+        return _loss.l1_ssim(c, target, lambda_dssim)
+    raise RuntimeError("l1_ssim_loss runs on an MI355X only (no CPU fallback)")
+
+
 def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
     """The importable-math subset of model/loss.py:89-109: clamped MSE + scale and opacity
     regularisers (exercises all three gradient routes into the render backward)."""
@@ -58,13 +67,27 @@ def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
         + w_opacity * (o * (1 - o)).mean()
 
 
+_ONES = {}
+
+
+def _unit_gradient(loss):
+    """A cached 1.0 of the loss's device/dtype: `loss.backward()` would launch a fill kernel for it every step."""
+    if loss.dim() != 0:
+        return None
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return one
+
+
 def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad_norm=0.1):
     """One step (trainer.py:134-175).  With a DataParallelSplat model the gradient all-reduce
     fires inside backward(); clipping then sees the averaged gradients, like DDP."""
     optimizer.zero_grad()
     outputs = model(camera_poses, target.shape[-2:])
     loss = loss_fn(outputs, target)
-    loss.backward()
+    loss.backward(gradient=_unit_gradient(loss))
     if max_grad_norm > 0 and not hasattr(optimizer, "max_grad_norm"):      # the fused optimizer clips inside step()
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()

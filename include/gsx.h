@@ -71,9 +71,11 @@ int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* total_de
  * _render_chunk (:110-115, :128-130) and adds the footprint rectangle (no counterpart in the
  * reference: it evaluates every Gaussian at every pixel).  order[r] = Gaussian composited r-th.
  * pre: from gsx_project_fwd.  rec: N x GSX_REC_FLOATS floats (layout: gsx_constants.h);
- * tiles_touched: N (rank order); rank_of: N, inverse of order (rank_of[order[r]] = r). */
+ * tiles_touched: N (rank order); rank_of: N, inverse of order (rank_of[order[r]] = r).
+ * tt_block_sums (nullable): ceil(N / 256) u64, sums of tiles_touched over consecutive groups of 256 ranks; handed to
+ * gsx_bin_count they save its reduction launch. */
 int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
-                      float* rec, uint32_t* tiles_touched, uint32_t* rank_of, void* stream);
+                      float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, void* stream);
 
 /* ---- binning: scan tiles_touched -> offsets, emit (tile, rank) instances, sort them by tile
  * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), cut tile
@@ -96,12 +98,13 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
  * gsx_bin_count: offsets = exclusive scan of tiles_touched, *total_dev (device, u64) = instance count D;
  *   if D_pinned_host != NULL the count is also copied there asynchronously (pinned host memory; valid once the
  *   caller has synchronised on an event recorded after this call).  ws: gsx_scan_workspace_bytes(N).
+ *   tt_block_sums: from gsx_build_records (the scan is then one launch), or NULL.
  * gsx_bin_emit_sort: everything after the count, with D read from *total_dev ON THE DEVICE and clamped to
  *   `capacity` (which sizes the launches): no host synchronisation.  If D turns out to exceed capacity the
  *   results are truncated (never out of bounds); the caller detects that from the count and calls again with
  *   larger buffers.  ws: gsx_bin_workspace_bytes(N, capacity).  Size chunk_state / partials / launch grids from
  *   capacity (gsx_max_chunks(capacity, H, W)), not from D. */
-int gsx_bin_count(const uint32_t* tiles_touched, int32_t N, uint32_t* offsets, uint64_t* total_dev,
+int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, int32_t N, uint32_t* offsets, uint64_t* total_dev,
                   int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream);
 int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                       int64_t capacity, const uint64_t* total_dev,
@@ -187,6 +190,19 @@ int gsx_image_loss_fwd(int32_t kind, const float* pred, const float* target, int
                        float* loss, void* ws, size_t ws_bytes, void* stream);
 int gsx_image_loss_bwd(int32_t kind, const float* pred, const float* target, int64_t n,
                        const float* upstream, float* d_pred, void* stream);
+
+/* ---- L1 + D-SSIM: (1 - lambda) * mean |pred - target| + lambda * (1 - mean SSIM(pred, target)), the criterion
+ * BASELINE config 2 names ("render + L1/SSIM backward").  No counterpart in the reference (its SSIM is
+ * a scikit-image metric, model/evaluation.py:97-105; fact 9 of SURVEY 0): the usual splatting form -- per-plane 11x11
+ * Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2.  pred/target: planes x H x W (planes = B*3).
+ * fwd writes loss3[0] = the loss, loss3[1] = mean |pred - target|, loss3[2] = mean SSIM (device) and leaves the three
+ * derivative maps the backward needs in ws (device, gsx_l1_ssim_workspace_bytes: 12 B per element + partial sums);
+ * bwd must get the same ws, untouched, and writes d_pred = dLoss/dpred * upstream[0] (NULL means 1). */
+size_t gsx_l1_ssim_workspace_bytes(int32_t planes, int32_t H, int32_t W);
+int gsx_l1_ssim_fwd(const float* pred, const float* target, int32_t planes, int32_t H, int32_t W, float lambda_dssim,
+                    float* loss3, void* ws, size_t ws_bytes, void* stream);
+int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int32_t H, int32_t W, float lambda_dssim,
+                    const float* upstream, const void* ws, size_t ws_bytes, float* d_pred, void* stream);
 
 /* ---- maintenance of the parameter buffers (model/gaussian_splatting.py:346-369, :404-418).
  * prune_gaussians = gsx_keep_flags (keep[i] = opacity[i] > threshold) -> gsx_scan_u32 (offsets, kept count) ->

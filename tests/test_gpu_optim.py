@@ -86,6 +86,89 @@ def test_fused_image_loss_matches_torch(kind, shape, offset):
         assert (xa.grad - xb.grad).abs().max().item() <= 1e-6 * xa.grad.abs().max().item()
 
 
+def _torch_ssim(img1, img2, window_size=11, sigma=1.5):
+    """The usual splatting SSIM in plain torch fp32 (per-channel 11x11 Gaussian window, zero padding): the restatement the
+    fused kernels are checked against (the reference has no SSIM loss; parity unpinned by it)."""
+    import math
+    C = img1.shape[-3]
+    gauss = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)], dtype=torch.float32)
+    gauss = (gauss / gauss.sum()).unsqueeze(1)
+    w2 = (gauss @ gauss.t()).unsqueeze(0).unsqueeze(0)
+    window = w2.expand(C, 1, window_size, window_size).contiguous().to(img1.device)
+    conv = lambda z: torch.nn.functional.conv2d(z, window, padding=window_size // 2, groups=C)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = conv(img1 * img1) - mu1_sq; s2 = conv(img2 * img2) - mu2_sq; s12 = conv(img1 * img2) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 37, 53), (2, 3, 64, 48), (1, 3, 16, 16), (1, 1, 5, 70)])
+@pytest.mark.parametrize("lam", [0.2, 1.0])
+def test_fused_l1_ssim_matches_torch(shape, lam):
+    """gsx_l1_ssim_fwd/bwd (BASELINE config 2's "L1/SSIM") against conv2d + autograd in fp32, with the backward run in
+    float64 as the yardstick.  Tolerances: loss 2e-6 absolute; gradient 2e-5 of its max (fp32 cancellation in
+    sigma = E[x^2] - mu^2 is the same on both sides; the fp32 torch backward is itself ~1e-5 from the fp64 one)."""
+    from gaussian_splatting_amd import loss as gl
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.rand(shape, generator=g); t = (x + 0.25 * torch.randn(shape, generator=g)).clamp(0, 1)
+    t[..., :3, :3] = x[..., :3, :3]                               # exact ties in the L1 term
+    xa = x.to(dev).requires_grad_(True); xb = x.to(dev).requires_grad_(True); xd = x.double().to(dev).requires_grad_(True)
+    td = t.to(dev)
+    la = (1 - lam) * (xa - td).abs().mean() + lam * (1 - _torch_ssim(xa, td))
+    ld = (1 - lam) * (xd - td.double()).abs().mean() + lam * (1 - _torch_ssim_f64(xd, td.double()))
+    lb, terms = gl.l1_ssim(xb, td, lam, return_terms=True)
+    (la * 2.0).backward(); (lb * 2.0).backward(); (ld * 2.0).backward()
+    assert abs(float(lb) - float(ld)) <= 2e-6, (float(lb), float(ld), float(la))
+    assert abs(float(terms[1]) - float((xd - td.double()).abs().mean())) <= 1e-6
+    assert abs(float(terms[2]) - (1 - (float(ld) - (1 - lam) * float(terms[1])) / lam)) <= 1e-5
+    ref = xd.grad.float()
+    scale = ref.abs().max().item()
+    err = (xb.grad - ref).abs().max().item(); err_torch = (xa.grad - ref).abs().max().item()
+    assert err <= 2e-5 * scale, (err, err_torch, scale)
+
+
+def _torch_ssim_f64(img1, img2):
+    import math
+    C = img1.shape[-3]
+    gauss = torch.tensor([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    gauss = (gauss / gauss.sum()).double().unsqueeze(1)           # the fp32 window, applied in double
+    window = (gauss @ gauss.t()).expand(C, 1, 11, 11).contiguous().to(img1.device)
+    conv = lambda z: torch.nn.functional.conv2d(z, window, padding=5, groups=C)
+    mu1, mu2 = conv(img1), conv(img2)
+    s1 = conv(img1 * img1) - mu1 * mu1; s2 = conv(img2 * img2) - mu2 * mu2; s12 = conv(img1 * img2) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))).mean()
+
+
+def test_config2_step_with_l1_ssim():
+    """BASELINE config 2 in miniature (its distribution at 3000 Gaussians, 96x80): one trainer step with the fused L1/SSIM
+    criterion against the same step with the torch restatement of the criterion on the same render path."""
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.scenes import synth_scene, CONFIGS
+    from gaussian_splatting_amd.trainer import make_optimizer, train_step, l1_ssim_loss
+    dev = torch.device("cuda:0")
+    _, _, _, seed, s_lo, s_hi, zq = CONFIGS["c2"]
+    params = synth_scene(3000, seed, s_lo * 4, s_hi * 4, zq)          # scales x4: the image is 1/8 of 800 px wide
+    H, W = 80, 96
+    pose = torch.eye(4); pose[2, 3] = 2.0
+    target = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    torch_loss = lambda out, tgt: 0.8 * (out['rendered_images'] - tgt).abs().mean() + 0.2 * (1 - _torch_ssim(out['rendered_images'], tgt))
+    res = []
+    for fn in (l1_ssim_loss, torch_loss):
+        m = GaussianSplat(3000)
+        m.load_state_dict({k: torch.from_numpy(params[k]) for k in ("positions", "scales", "rotations", "opacity", "features")})
+        m = m.to(dev)
+        opt = make_optimizer(m, fused_clip_norm=0.1, write_clipped_grad=True)
+        loss = train_step(m, opt, pose[None].to(dev), target, fn, max_grad_norm=0.1)
+        res.append((float(loss), {k: v.grad.clone() for k, v in m.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), k
+
+
 def test_fused_image_loss_rejects_cpu():
     from gaussian_splatting_amd import loss as gl
     with pytest.raises(RuntimeError):

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsx.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.gsx_abi_version() == 8
+    assert lib.gsx_abi_version() == 9
     assert lib.gsx_strerror(-2).decode().startswith("instance buffers")
     # pure host helpers (no GPU): workspace sizes and the chunk bound
     assert lib.gsx_sort_workspace_bytes(1 << 20) >= 256 * 256 * 4
@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     assert lib.gsx_project_fwd(*nul, 5, *nul) == _lib.GSX_E_INVALID
     assert lib.gsx_project_fwd(*nul, -1, *nul) == _lib.GSX_E_INVALID
     assert lib.gsx_project_fwd(*nul, 0, *nul) == _lib.GSX_OK
-    assert lib.gsx_build_records(None, None, 4, 70000, 8, None, None, None, None) == _lib.GSX_E_INVALID
+    assert lib.gsx_build_records(None, None, 4, 70000, 8, None, None, None, None, None) == _lib.GSX_E_INVALID
     assert lib.gsx_sort_pairs_u32(None, None, None, None, None, None, 10, 0, 33, None, 0, None) == _lib.GSX_E_INVALID
 
 
