@@ -80,6 +80,246 @@ __global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restri
 
 static int tile_bits(int n_tiles) { int b = 1; while ((1 << b) < n_tiles) b++; return b; }
 
+// ------------------------------------------------------------------------------------------
+// One-pass stable counting sort of the instances by tile id, for images of up to 4096 tiles (config 3: 64 x 64).
+// The generic 8-bit LSD sort needs two passes of three launches here, plus a launch of binary searches for the tile
+// ranges and one for the chunk table; with the whole tile id as ONE 12-bit digit the per-tile totals ARE the range
+// lengths, so the pass is: histogram -> scan down the table's columns -> scatter (whose workgroup 0 also writes the
+// ranges and the chunk table).  3 launches instead of 8 and one trip of the instances through HBM instead of two.
+// Stability (each tile's list stays in rank order) comes from wave-private digit counters, as in gsx_sort.hip: 16 waves
+// x 4096 u16 counters = 128 KB of the CU's 160 KB LDS, so one workgroup of 1024 threads per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int kTsBits = 12, kTsDigits = 1 << kTsBits;
+constexpr int kTsThreads = 1024, kTsWaves = kTsThreads / 64;
+constexpr int kTsItems = 16;                                  // most keys per thread (the device picks 2..16 from the count: ts_items)
+constexpr int kTsSegDigits = 64;                              // column-scan workgroup: 64 digits x 16 row segments
+
+__device__ __forceinline__ int64_t ts_count(const uint64_t* __restrict__ total_dev, int64_t capacity)
+{
+    const uint64_t d = *total_dev;
+    return d < (uint64_t)capacity ? (int64_t)d : capacity;
+}
+// Keys per workgroup, decided on the device from the instance count: spread the keys over (at most) one workgroup per
+// CU -- the scatter's fully divergent stores retire about one lane per cycle per CU, so idle CUs are lost time, while a
+// 257th workgroup would wait for a whole CU (the LDS holds one) -- in steps of one key per thread.
+constexpr int kTsCus = 256;
+__device__ __host__ __forceinline__ int ts_items(int64_t n)
+{
+    const int64_t it = (n + (int64_t)kTsCus * kTsThreads - 1) / ((int64_t)kTsCus * kTsThreads);
+    return it < 2 ? 2 : (it > kTsItems ? kTsItems : (int)it);
+}
+
+// hist[b][d] = number of keys of workgroup b that belong to tile d (rows of workgroups past the count are never read)
+__global__ __launch_bounds__(kTsThreads) void tile_hist_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ total_dev,
+                                                               int64_t capacity, int n_tiles, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_hist[kTsDigits];
+    const int64_t n = ts_count(total_dev, capacity);
+    const int items = ts_items(n);
+    const int64_t base = (int64_t)blockIdx.x * items * kTsThreads;
+    if (base >= n) return;
+    for (int d = threadIdx.x; d < n_tiles; d += kTsThreads) s_hist[d] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {
+        const int64_t i = base + k * kTsThreads + threadIdx.x;
+        if (k < items && i < n) atomicAdd(&s_hist[keys[i] & (kTsDigits - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * kTsDigits;
+    for (int d = threadIdx.x; d < n_tiles; d += kTsThreads) row[d] = s_hist[d];
+}
+
+// exclusive scan down every column of hist (over the workgroups that hold keys), column total -> totals[d].
+// One workgroup = 64 columns x 16 segments of rows: sum the segment, exchange, rewrite the segment as prefixes.
+__global__ __launch_bounds__(kTsThreads) void tile_colscan_kernel(uint32_t* __restrict__ hist, const uint64_t* __restrict__ total_dev,
+                                                                  int64_t capacity, int n_tiles, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_seg[kTsWaves][kTsSegDigits];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int d = blockIdx.x * kTsSegDigits + lane;
+    const int64_t n = ts_count(total_dev, capacity);
+    const int64_t tile = (int64_t)ts_items(n) * kTsThreads;
+    const int nb = (int)((n + tile - 1) / tile);
+    const int per = (nb + kTsWaves - 1) / kTsWaves;
+    const int r0 = min(seg * per, nb), r1 = min(r0 + per, nb);
+    const bool live = d < n_tiles;
+    uint32_t sum = 0;
+    if (live) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const uint32_t a = hist[(size_t)r * kTsDigits + d], b = hist[(size_t)(r + 1) * kTsDigits + d];
+            const uint32_t c = hist[(size_t)(r + 2) * kTsDigits + d], e = hist[(size_t)(r + 3) * kTsDigits + d];
+            sum += (a + b) + (c + e);
+        }
+        for (; r < r1; r++) sum += hist[(size_t)r * kTsDigits + d];
+    }
+    s_seg[seg][lane] = sum;
+    __syncthreads();
+    if (!live) return;
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < kTsWaves; s2++) { const uint32_t v = s_seg[s2][lane]; if (s2 < seg) run += v; tot += v; }
+    if (seg == 0) totals[d] = tot;
+    for (int r = r0; r < r1; r++) {
+        uint32_t* cell = hist + (size_t)r * kTsDigits + d;
+        const uint32_t v = *cell; *cell = run; run += v;
+    }
+}
+
+// exclusive scan of one value per thread over a 1024-thread workgroup
+__device__ __forceinline__ uint32_t block1024_excl_scan(uint32_t v, uint32_t* s_wave /*[16]*/, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kTsWaves; w++) { const uint32_t x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                  const uint64_t* __restrict__ total_dev, int64_t capacity, int n_tiles,
+                                                                  const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
+                                                                  uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base)
+{
+    __shared__ uint16_t s_cnt[kTsWaves][kTsDigits];      // per-wave digit counts, then per-wave offsets inside the workgroup
+    __shared__ uint32_t s_base[kTsDigits];               // per tile: global slot minus position inside the workgroup
+    __shared__ uint16_t s_lstart[kTsDigits];             // per tile: position of its first key inside the workgroup
+    __shared__ uint32_t s_scan[kTsWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = ts_count(total_dev, capacity);
+    const int items = ts_items(n);
+    const int64_t base = (int64_t)blockIdx.x * items * kTsThreads;
+    const bool active = base < n;
+    if (!active && blockIdx.x != 0) return;
+    // 32-bit positions inside the workgroup from here on (uniform 64-bit base + per-lane u32 offset: fewer registers)
+    const int64_t left = n - base;
+    const uint32_t here = active ? (uint32_t)(left < (int64_t)items * kTsThreads ? left : (int64_t)items * kTsThreads) : 0u;
+    const uint32_t* kin = keys_in + (active ? base : 0);
+    const uint32_t* vin = vals_in + (active ? base : 0);
+    const uint32_t wlane = (uint32_t)(wave * items * 64 + lane);        // each wave owns a contiguous run of keys
+    uint32_t key[kTsItems];
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {                                // issued first: in flight during the scans below
+        const uint32_t li = wlane + k * 64;
+        key[k] = (k < items && li < here) ? (kin[li] & (kTsDigits - 1)) : 0u;
+    }
+    // tile bases = exclusive scan of the column totals; thread t owns tiles 4t .. 4t+3
+    uint32_t tv[4], db[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int d = 4 * tid + i; tv[i] = d < n_tiles ? totals[d] : 0u; }
+    uint32_t tot;
+    const uint32_t ex = block1024_excl_scan((tv[0] + tv[1]) + (tv[2] + tv[3]), s_scan, &tot);
+    db[0] = ex; db[1] = db[0] + tv[0]; db[2] = db[1] + tv[1]; db[3] = db[2] + tv[2];
+    if (blockIdx.x == 0) {
+        // what ranges_kernel and the chunk-table scan did: ranges[t] = [first, last), chunk_base = scan of ceil(len / GSX_CHUNK)
+        uint32_t cc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int d = 4 * tid + i;
+            cc[i] = d < n_tiles ? (tv[i] + GSX_CHUNK - 1) / GSX_CHUNK : 0u;
+            if (d < n_tiles) { ranges[2 * d] = db[i]; ranges[2 * d + 1] = db[i] + tv[i]; }
+        }
+        uint32_t ctot;
+        uint32_t cex = block1024_excl_scan((cc[0] + cc[1]) + (cc[2] + cc[3]), s_scan, &ctot);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int d = 4 * tid + i; if (d < n_tiles) chunk_base[d] = cex; cex += cc[i]; }
+        if (tid == 0) chunk_base[n_tiles] = ctot;
+        if (!active) return;
+    }
+    const uint32_t* prow = hist_scanned + (size_t)blockIdx.x * kTsDigits;
+    uint32_t gb[4];                                                     // first global slot of this workgroup's keys of my 4 tiles
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int d = 4 * tid + i; gb[i] = db[i] + (d < n_tiles ? prow[d] : 0u); }
+    {
+        uint4* z = reinterpret_cast<uint4*>(&s_cnt[0][0]);
+        constexpr int kVec = kTsWaves * kTsDigits * 2 / 16;
+        for (int i = tid; i < kVec; i += kTsThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    uint16_t* cnt = s_cnt[wave];
+    // from here key[k] also carries the key's position: tile id in bits 0..11, position (< 16384) above
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {
+        if (k < items) {                                                // uniform
+            const bool valid = wlane + k * 64 < here;
+            const uint32_t d = key[k];
+            uint32_t rank, count;
+            wave_match_rank<kTsBits>(d, valid, rank, count);
+            const uint32_t old = cnt[d];                               // every lane reads before the leader writes
+            if (valid && rank == 0) cnt[d] = (uint16_t)(old + count);
+            key[k] = d | ((old + rank) << kTsBits);
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // one round at a time: interleaved rounds spill (128 VGPRs at 1024 threads)
+    }
+    __syncthreads();
+    // per tile: exclusive prefix of the 16 waves' counts (fits 16 bits: <= 16384 keys per workgroup).  Thread t owns tiles
+    // 4t .. 4t+3 = one uint2 of packed u16 pairs per wave row.
+    uint32_t t01 = 0, t23 = 0;
+    {
+        uint2* c2 = reinterpret_cast<uint2*>(&s_cnt[0][0]);
+#pragma unroll
+        for (int w = 0; w < kTsWaves; w++) {
+            const uint2 c = c2[w * (kTsDigits / 4) + tid];
+            c2[w * (kTsDigits / 4) + tid] = make_uint2(t01, t23);
+            t01 += c.x; t23 += c.y;
+        }
+    }
+    // position of each tile's first key inside the workgroup's tile-sorted order, and what turns such a position into
+    // the global slot: the keys go through LDS in that order so that the stores to HBM are runs of consecutive addresses
+    // (scattered 4-byte stores cost one L2 transaction each: 2 per key, ~6 us per million keys on the whole chip)
+    const uint32_t c0 = t01 & 0xffffu, c1 = t01 >> 16, c2n = t23 & 0xffffu, c3 = t23 >> 16;
+    uint32_t ltot;
+    const uint32_t l0 = block1024_excl_scan((c0 + c1) + (c2n + c3), s_scan, &ltot);
+    const uint32_t l1 = l0 + c0, l2 = l1 + c1, l3 = l2 + c2n;
+    reinterpret_cast<uint2*>(s_lstart)[tid] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    reinterpret_cast<uint4*>(s_base)[tid] = make_uint4(gb[0] - l0, gb[1] - l1, gb[2] - l2, gb[3] - l3);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++)
+        if (k < items) { const uint32_t d = key[k] & (kTsDigits - 1); key[k] += ((uint32_t)s_lstart[d] + (uint32_t)cnt[d]) << kTsBits; }
+    __syncthreads();                                                    // the counters are dead: their LDS stages the keys
+    uint32_t* s_val = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);        // 16384 x 4 B
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(s_val + kTsThreads * kTsItems);      // 16384 x 2 B
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {
+        const uint32_t li = wlane + k * 64;                             // the values are read only now: 16 registers fewer across the ranking
+        if (k < items && li < here) { const uint32_t pos = key[k] >> kTsBits; s_val[pos] = vin[li]; s_key[pos] = (uint16_t)(key[k] & (kTsDigits - 1)); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {
+        const uint32_t i = (uint32_t)(k * kTsThreads + tid);
+        if (k < items && i < here) {
+            const uint32_t d = s_key[i];
+            const uint32_t dst = s_base[d] + i;
+            keys_out[dst] = d;
+            vals_out[dst] = s_val[i];
+        }
+    }
+}
+
+// workgroups to launch for `capacity` instances: the device picks the keys per workgroup from the real count
+static int64_t tile_sort_blocks(int64_t capacity)
+{
+    const int64_t nb = ceil_div(capacity > 0 ? capacity : 1, (int64_t)ts_items(capacity) * kTsThreads);
+    return nb;
+}
+static size_t tile_sort_ws_bytes(int64_t capacity)
+{
+    int64_t nb = tile_sort_blocks(capacity);
+    if (nb < kTsCus) nb = kTsCus;
+    return align_up((size_t)nb * kTsDigits * 4) + align_up((size_t)kTsDigits * 4);
+}
+
 }  // namespace gsx
 
 using namespace gsx;
@@ -92,7 +332,9 @@ GSX_API size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity)
     size_t a = gsx_scan_workspace_bytes(N > 0 ? N : 1);
     size_t b = sort_ws_bytes_internal(capacity > 0 ? capacity : 1);
     size_t c = chunk_scan_ws_bytes();
+    size_t t = tile_sort_ws_bytes(capacity);
     size_t m = a > b ? a : b;
+    if (t > m) m = t;
     return 256 + (m > c ? m : c);
 }
 
@@ -128,6 +370,26 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
     const int bits = tile_bits(n_tiles);
+    if (n_tiles <= kTsDigits) {
+        // one 12-bit pass; ranges and chunk table come out of the scatter's workgroup 0
+        // grid for the largest workgroup count any instance count <= capacity can need (fewer instances -> fewer keys per
+        // workgroup, up to one workgroup per CU; past 256 x 16384 instances the workgroups stay at 16384 keys)
+        int64_t nbl = tile_sort_blocks(capacity);
+        const int64_t small = ceil_div(capacity, 2 * kTsThreads);        // workgroups of the smallest tile
+        if (nbl < kTsCus) nbl = small < kTsCus ? small : kTsCus;
+        const unsigned nb = (unsigned)nbl;
+        uint32_t* hist = (uint32_t*)sub_ws;
+        uint32_t* totals = (uint32_t*)((char*)sub_ws + align_up((size_t)nb * kTsDigits * 4));
+        if (N > 0) {
+            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
+            tile_hist_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
+        }
+        tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
+        tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
+                                                                    hist, totals, ranges, chunk_base);
+        GSX_LAUNCH_CHECK();
+        return GSX_OK;
+    }
     const int passes = (bits + 7) / 8;
     // emit into the buffer the sort does NOT write first, so that the last pass lands in *_sorted
     uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;

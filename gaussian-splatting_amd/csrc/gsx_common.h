@@ -45,4 +45,25 @@ __device__ __forceinline__ float row_sum16(float v)
     return v;
 }
 
+// ---- wave64 match-any on the low BITS bits of d: rank = number of lower valid lanes with the same digit (stable
+// order), count = number of valid lanes with it.  Per bit: one v_bfe_i32 (m = all ones where the lane's bit is 0), one
+// compare for the ballot, and p &= ballot ^ m on both halves (lanes whose bit is 1 keep the ballot's lanes, the others its
+// complement) -- no 64-bit selects, which cost two v_cndmask plus two moves per bit on a one-SGPR-per-instruction ISA.
+template <int BITS>
+__device__ __forceinline__ void wave_match_rank(uint32_t d, bool valid, uint32_t& rank, uint32_t& count)
+{
+    const unsigned long long vm = __ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+    const uint32_t nd = ~d;
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)nd, b, 1);
+        const unsigned long long bal = __ballot(m == 0u);
+        plo &= (uint32_t)bal ^ m;
+        phi &= (uint32_t)(bal >> 32) ^ m;
+    }
+    rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    count = __popc(plo) + __popc(phi);
+}
+
 }  // namespace gsx

@@ -200,22 +200,26 @@ __global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restr
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// Stable scatter of one 4096-key tile.  Each wave owns a CONTIGUOUS quarter of the tile (16 rounds of 64
+// Stable scatter of one 2048-key tile.  Each wave owns a CONTIGUOUS quarter of the tile (8 rounds of 64
 // consecutive keys), ranks its keys against its own running digit counters in LDS (same-wave LDS operations
-// retire in order, so the rounds need no barrier), and only then do the four waves meet once to turn the
-// counters into global slots: 3 barriers per tile instead of 4 per round.
+// retire in order, so the rounds need no barrier), and only then do the four waves meet to turn the counters into
+// positions.  The pairs then pass through LDS in digit order, so that the stores to HBM are runs of consecutive
+// addresses: a scattered 4-byte store costs one L2 transaction, and 2 per key is what bounded this kernel.
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                int64_t n, const uint64_t* __restrict__ n_dev, int shift, uint32_t mask,
                                                                const uint32_t* __restrict__ hist_scanned, uint32_t nb,
                                                                const uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_cnt[4][kRadix];     // per-wave digit counts, then per-wave global base slots
+    __shared__ uint32_t s_cnt[4][kRadix];     // per-wave digit counts, then per-wave first positions inside the tile
+    __shared__ uint32_t s_delta[kRadix];      // per digit: global slot minus position inside the tile
+    __shared__ uint32_t s_key[kSortTile], s_val[kSortTile];
     n = device_count(n_dev, n);
     __shared__ uint32_t s_scan[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int kWaveKeys = kSortTile / 4;  // 1024
-    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * kWaveKeys;
+    constexpr int kWaveKeys = kSortTile / 4;  // 512
+    const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = tile0 + (int64_t)wave * kWaveKeys;
     uint32_t tot;
     const uint32_t digit_base = block_excl_scan_u32(totals[tid], s_scan, &tot);   // two barriers inside
     s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
@@ -228,38 +232,44 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
         val[k] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();                          // counters zeroed
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t* cnt = s_cnt[wave];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         const bool valid = base + k * 64 + lane < n;
         const uint32_t d = (key[k] >> shift) & mask;
-        // lanes of this wave holding the same digit (stable: lane order == key order)
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const uint32_t rank = __popcll(peers & lt_mask);
+        uint32_t rank, count;
+        wave_match_rank<kRadixBits>(d, valid, rank, count);             // lanes of this wave holding the same digit (stable: lane order == key order)
         const uint32_t old = cnt[d];                                   // every lane reads before the leader writes
-        if (valid && rank == 0) cnt[d] = old + __popcll(peers);
+        if (valid && rank == 0) cnt[d] = old + count;
         loc[k] = old + rank;
     }
     __syncthreads();
     {
-        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid];
-        const uint32_t r0 = digit_base + hist_scanned[(size_t)tid * nb + blockIdx.x];
-        s_cnt[0][tid] = r0; s_cnt[1][tid] = r0 + c0; s_cnt[2][tid] = r0 + c0 + c1; s_cnt[3][tid] = r0 + c0 + c1 + c2;
+        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        uint32_t ltot;
+        const uint32_t lstart = block_excl_scan_u32((c0 + c1) + (c2 + c3), s_scan, &ltot);      // digit tid's first position inside the tile
+        s_cnt[0][tid] = lstart; s_cnt[1][tid] = lstart + c0; s_cnt[2][tid] = lstart + c0 + c1; s_cnt[3][tid] = lstart + c0 + c1 + c2;
+        s_delta[tid] = digit_base + hist_scanned[(size_t)tid * nb + blockIdx.x] - lstart;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         if (base + k * 64 + lane < n) {
-            const uint32_t dst = cnt[(key[k] >> shift) & mask] + loc[k];
-            keys_out[dst] = key[k];
-            vals_out[dst] = val[k];
+            const uint32_t pos = cnt[(key[k] >> shift) & mask] + loc[k];
+            s_key[pos] = key[k]; s_val[pos] = val[k];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - tile0;
+    const uint32_t here = (uint32_t)(left < (int64_t)kSortTile ? (left > 0 ? left : 0) : (int64_t)kSortTile);
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t i = (uint32_t)(k * kBlock + tid);
+        if (i < here) {
+            const uint32_t kk = s_key[i];
+            const uint32_t dst = s_delta[(kk >> shift) & mask] + i;
+            keys_out[dst] = kk;
+            vals_out[dst] = s_val[i];
         }
     }
 }

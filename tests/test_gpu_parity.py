@@ -174,6 +174,8 @@ CASES = {
     "c3_50000_320x320_orbit": lambda: (synth_scene(50000, 5, 0.001, 0.005), orbit_pose(15), 320, 320),
     "c5_6000_480x270_ties": lambda: (synth_scene(6000, 8, 0.01, 0.1, zq=64.0), pose_tz(2.0), 270, 480),
     "opacity_out_of_range": lambda: (synth_scene(3000, 9, 0.005, 0.03, o_lo=-0.5, o_hi=1.5), pose_tz(2.0), 96, 128),
+    # 66 x 65 = 4290 tiles: beyond the one-pass 12-bit tile sort, i.e. the generic two-pass radix path + ranges kernel
+    "more_than_4096_tiles_1056x1040": lambda: (synth_scene(4000, 12, 0.004, 0.03), pose_tz(2.0), 1040, 1056),
     "empty_screen": lambda: (synth_scene(500, 10, 0.001, 0.002), _shifted_pose(50.0), 64, 64),   # D == 0
 }
 
