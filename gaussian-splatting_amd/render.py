@@ -71,7 +71,10 @@ class _Scratch:
         return self.capacity.get(dev, max(4 * n, 1 << 16))
 
     def grow(self, dev, d):
-        self.capacity[dev] = int(d * 1.25) + 4096
+        self.capacity[dev] = int(d) + max(int(d) >> 3, 4096)
+        # every per-view buffer changes size with the capacity: hand the cached blocks of the old size back first, or
+        # at config-5 scale (tens of GB per buffer) the allocator's reserved-but-unusable blocks exhaust the device
+        torch.cuda.empty_cache()
 
     def count_slot(self, dev):
         """(pinned int64[1], event) for the asynchronous read-back of the instance count"""
@@ -220,7 +223,7 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
 class ViewState:
     """Everything one view's backward needs (kept alive by the autograd node)."""
     __slots__ = ("pose", "order", "rank_of", "rec", "tt", "offsets", "ranks", "ranges", "chunk_base", "chunk_state", "max_chunks",
-                 "state", "D", "H", "W")
+                 "state", "D", "H", "W", "cap")
 
 
 def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True):
@@ -249,12 +252,13 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
             raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
         if D <= cap:
             break
+        del tiles, ranks, ranges, chunk_base, rgb, alpha, dmap, state, chunk_state     # truncated results of the attempt
         _scratch.grow(dev, D)
     _last_D = D
     vs = ViewState()
     vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, order, rank_of, rec, tt, offsets
     vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = ranks, ranges, chunk_base, chunk_state, max_chunks
-    vs.state, vs.D, vs.H, vs.W = state, D, H, W
+    vs.state, vs.D, vs.H, vs.W, vs.cap = state, D, H, W, cap
     vs_extra = dict(tiles=tiles)
     return (rgb, alpha, dmap, mean2d, depth, cov2d), vs, vs_extra
 
@@ -266,7 +270,9 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
     n = positions.shape[0]; dev = positions.device
     partials = None
     if d_rgb is not None and vs.D > 0:
-        partials = torch.empty(vs.D, 9, dtype=torch.float32, device=dev)
+        # sized by the buffers' capacity, not by this view's count: the same size every step, so torch's caching allocator
+        # hands the block back instead of freeing and re-allocating tens of GB per view at config-5 scale
+        partials = torch.empty(max(vs.D, getattr(vs, "cap", 0) or 0), 9, dtype=torch.float32, device=dev)
         with _stage("composite_bwd"):
             L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.chunk_base), _ptr(vs.offsets),
                                           n, vs.H, vs.W, vs.max_chunks, _ptr(vs.chunk_state), _ptr(vs.state),
