@@ -55,7 +55,7 @@ def lib():
     L.gsx_abi_version.restype = C.c_int
     L.gsx_project_fwd.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]
     L.gsx_sort_workspace_bytes.restype = _sz; L.gsx_sort_workspace_bytes.argtypes = [_i64]
-    L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _sz, _p]
+    L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _sz, _p]
     L.gsx_scan_workspace_bytes.restype = _sz; L.gsx_scan_workspace_bytes.argtypes = [_i64]
     L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
     L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p]

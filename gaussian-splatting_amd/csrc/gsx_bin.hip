@@ -7,7 +7,7 @@
 namespace gsx {
 
 int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, const uint64_t*, int, int,
-                        void*, size_t, hipStream_t);
+                        void*, size_t, hipStream_t, int check_bit = 32, uint64_t* mismatch_dev = nullptr);
 int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0);
 size_t sort_ws_bytes_internal(int64_t n);
 
@@ -352,7 +352,7 @@ GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_bloc
     if (N > 0 && (!tiles_touched || !offsets || !ws || ws_bytes < gsx_scan_workspace_bytes(N))) return GSX_E_INVALID;
     int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st, tt_block_sums, kBlock);     // N == 0: total = 0
     if (s != GSX_OK) return s;
-    if (D_pinned_host) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 8, hipMemcpyDeviceToHost, st));
+    if (D_pinned_host) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 16, hipMemcpyDeviceToHost, st));   // D and the caller's word
     return GSX_OK;
 }
 

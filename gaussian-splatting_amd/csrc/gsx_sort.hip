@@ -165,39 +165,57 @@ __device__ __forceinline__ int64_t device_count(const uint64_t* __restrict__ n_d
     return d < (uint64_t)n ? (int64_t)d : n;
 }
 
+// check_bit < 32 (first pass of a sort only): row kRadix of the table gets the workgroup's number of keys whose bits
+// [check_bit, 32) differ from keys[0]'s -- the caller's proof that a sort which skipped those bits was entitled to.
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ n_dev,
-                                                            int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nb)
+                                                            int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nb, int check_bit)
 {
     __shared__ uint32_t s_hist[kRadix];
+    __shared__ uint32_t s_mis[4];
     n = device_count(n_dev, n);
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const uint32_t ref = (check_bit < 32 && n > 0) ? (keys[0] >> check_bit) : 0u;
+    uint32_t mis = 0;
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         int64_t i = base + k * kBlock + threadIdx.x;
-        if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+        if (i < n) {
+            const uint32_t key = keys[i];
+            atomicAdd(&s_hist[(key >> shift) & mask], 1u);
+            if (check_bit < 32) mis += ((key >> check_bit) != ref) ? 1u : 0u;
+        }
+    }
+    if (check_bit < 32) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mis += __shfl_down(mis, d, 64);
+        if ((threadIdx.x & 63) == 0) s_mis[threadIdx.x >> 6] = mis;
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nb + blockIdx.x] = s_hist[threadIdx.x];
+    if (check_bit < 32 && threadIdx.x == 0) hist[(size_t)kRadix * nb + blockIdx.x] = (s_mis[0] + s_mis[1]) + (s_mis[2] + s_mis[3]);
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-workgroup counts in place, row total -> totals[d].
 // (hist + rowscan + scatter = 3 launches per pass; the scatter kernel turns the 256 totals into digit bases itself)
-__global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nb, uint32_t* __restrict__ totals)
+// Workgroup kRadix, when launched, adds up the mismatch row instead (radix_hist_kernel) -> *mismatch.
+__global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nb, uint32_t* __restrict__ totals,
+                                                               uint64_t* __restrict__ mismatch)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t* row = hist + (size_t)blockIdx.x * nb;
     uint32_t carry = 0;
+    const bool plain_sum = blockIdx.x == kRadix;
     for (uint32_t base = 0; base < nb; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = (i < nb) ? row[i] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(v, s_wave, &tot);
-        if (i < nb) row[i] = carry + ex;
+        if (i < nb && !plain_sum) row[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+    if (threadIdx.x == 0) { if (plain_sum) *mismatch = (uint64_t)carry; else totals[blockIdx.x] = carry; }
 }
 
 // Stable scatter of one 2048-key tile.  Each wave owns a CONTIGUOUS quarter of the tile (8 rounds of 64
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
 static size_t sort_ws_bytes(int64_t n)
 {
     int64_t nb = ceil_div(n > 0 ? n : 1, kSortTile);
-    int64_t hist_n = nb * kRadix;
+    int64_t hist_n = nb * (kRadix + 1);          // + the mismatch row of a checked sort
     return align_up((size_t)hist_n * 4) + align_up((size_t)kRadix * 4);
 }
 
@@ -288,19 +306,26 @@ static size_t sort_ws_bytes(int64_t n)
 // n_dev != NULL: the real count lives in device memory (clamped to n, which then only sizes the grids).
 int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_a, uint32_t* v_a,
                         uint32_t* k_b, uint32_t* v_b, int64_t n, const uint64_t* n_dev, int begin_bit, int end_bit,
-                        void* ws, size_t ws_bytes, hipStream_t st)
+                        void* ws, size_t ws_bytes, hipStream_t st, int check_bit, uint64_t* mismatch_dev)
 {
-    if (n <= 0) return GSX_OK;
+    if (n <= 0) { if (mismatch_dev) GSX_HIP(hipMemsetAsync(mismatch_dev, 0, 8, st)); return GSX_OK; }
     if (n >= (int64_t)0xFFFFFFFFll) return GSX_E_RANGE;
     if (ws_bytes < sort_ws_bytes(n)) return GSX_E_CAPACITY;
     const int passes = (end_bit - begin_bit + kRadixBits - 1) / kRadixBits;
     const uint32_t nb = (uint32_t)ceil_div(n, kSortTile);
-    const int64_t hist_n = (int64_t)nb * kRadix;
+    const int64_t hist_n = (int64_t)nb * (kRadix + 1);
     uint32_t* hist = (uint32_t*)ws;
     uint32_t* totals = (uint32_t*)((char*)ws + align_up((size_t)hist_n * 4));
+    const bool check = mismatch_dev != nullptr && check_bit < 32;
+    if (mismatch_dev && !check) GSX_HIP(hipMemsetAsync(mismatch_dev, 0, 8, st));      // nothing above bit 32 can differ
     if (passes == 0) {   // nothing to sort on: copy through
         GSX_HIP(hipMemcpyAsync(k_a, k_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         if (v_in) GSX_HIP(hipMemcpyAsync(v_a, v_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        if (check) {     // the check rides on a histogram launch
+            radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(k_in, n, n_dev, 0, 0u, hist, nb, check_bit);
+            radix_rowscan_kernel<<<dim3(kRadix + 1), dim3(kBlock), 0, st>>>(hist, nb, totals, mismatch_dev);
+            GSX_LAUNCH_CHECK();
+        }
         return GSX_OK;
     }
     const uint32_t* ks = k_in; const uint32_t* vs = v_in;
@@ -310,8 +335,9 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
         const int shift = begin_bit + p * kRadixBits;
         const int bits = (end_bit - shift) < kRadixBits ? (end_bit - shift) : kRadixBits;
         const uint32_t mask = (1u << bits) - 1u;
-        radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, n_dev, shift, mask, hist, nb);
-        radix_rowscan_kernel<<<dim3(kRadix), dim3(kBlock), 0, st>>>(hist, nb, totals);
+        const bool chk = check && p == 0;
+        radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, n, n_dev, shift, mask, hist, nb, chk ? check_bit : 32);
+        radix_rowscan_kernel<<<dim3(kRadix + (chk ? 1 : 0)), dim3(kBlock), 0, st>>>(hist, nb, totals, mismatch_dev);
         radix_scatter_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(ks, vs, kd, vd, n, n_dev, shift, mask, hist, nb, totals);
         GSX_LAUNCH_CHECK();
         ks = kd; vs = vd;
@@ -339,14 +365,14 @@ GSX_API size_t gsx_sort_workspace_bytes(int64_t n) { return sort_ws_bytes(n); }
 
 GSX_API int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
                                uint32_t* keys_tmp, uint32_t* values_tmp, int64_t n, int begin_bit, int end_bit,
-                               void* ws, size_t ws_bytes, void* stream)
+                               int check_bit, uint64_t* mismatch_dev, void* ws, size_t ws_bytes, void* stream)
 {
-    if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSX_E_INVALID;
+    if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit || check_bit < 0 || check_bit > 32) return GSX_E_INVALID;
     if (n == 0) return GSX_OK;
     if (!keys_in || !keys_out || !values_out || !keys_tmp || !values_tmp || !ws) return GSX_E_INVALID;
     if (keys_in == keys_out || keys_in == keys_tmp || keys_out == keys_tmp) return GSX_E_INVALID;
     return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, nullptr, begin_bit, end_bit,
-                               ws, ws_bytes, (hipStream_t)stream);
+                               ws, ws_bytes, (hipStream_t)stream, check_bit, mismatch_dev);
 }
 
 GSX_API size_t gsx_scan_workspace_bytes(int64_t n) { return align_up((size_t)ceil_div(n > 0 ? n : 1, kScanTile) * 8); }

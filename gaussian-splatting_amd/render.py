@@ -66,6 +66,7 @@ class _Scratch:
     def __init__(self):
         self.capacity = {}
         self.pinned = {}
+        self.depth_bits = {}      # per device: key bits the next depth sort covers (24 while the top byte is constant)
 
     def cap(self, dev, n):
         return self.capacity.get(dev, max(4 * n, 1 << 16))
@@ -77,17 +78,22 @@ class _Scratch:
         torch.cuda.empty_cache()
 
     def count_slot(self, dev):
-        """(pinned int64[1], event) for the asynchronous read-back of the instance count"""
+        """(pinned int64[2], event) for the asynchronous read-back of the instance count and the depth sort's mismatch count"""
         if dev not in self.pinned:
-            self.pinned[dev] = (torch.zeros(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+            self.pinned[dev] = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         return self.pinned[dev]
 
 
 _scratch = _Scratch()
 
 
-def depth_order(depth_keys):
-    """order[r] = index of the Gaussian composited r-th (descending depth, ties by index)."""
+DEPTH_CHECK_BIT = 24      # the depth sort skips its last pass (key bits 24..31) while those bits are the same for every Gaussian
+
+
+def depth_order(depth_keys, end_bit=32, mismatch=None):
+    """order[r] = index of the Gaussian composited r-th (descending depth, ties by index).
+    end_bit < 32 sorts on the low bits only -- valid iff the bits above are constant, which `mismatch` (device int64[1],
+    the number of keys whose bits [DEPTH_CHECK_BIT, 32) differ from the first key's) lets the caller verify afterwards."""
     lib = L.lib()
     n = depth_keys.numel()
     dev = depth_keys.device
@@ -99,7 +105,7 @@ def depth_order(depth_keys):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     with _stage("depth_sort"):
         L.check(lib.gsx_sort_pairs_u32(_ptr(depth_keys), None, _ptr(k_out), _ptr(order), _ptr(k_tmp), _ptr(v_tmp),
-                                       n, 0, 32, _ptr(ws), wsb, _stream()), "gsx_sort_pairs_u32")
+                                       n, 0, end_bit, DEPTH_CHECK_BIT, _ptr(mismatch), _ptr(ws), wsb, _stream()), "gsx_sort_pairs_u32")
     return order
 
 
@@ -160,14 +166,16 @@ def bin_instances(rec, tt, H, W):
     return offsets, bufs[0], bufs[1], ranges, chunk_base, int(D.value)
 
 
-def bin_count(tt):
+def bin_count(tt, total=None):
     """Enqueue scan(tiles_touched) and the asynchronous copy of the instance count to pinned host memory.
-    -> offsets, total_dev (device u64[1]), (pinned, event): the count is valid after event.synchronize()."""
+    -> offsets, total (device int64[2]: the count, and a word of the caller's that is copied along), (pinned, event):
+    the pinned copy is valid after event.synchronize()."""
     lib = L.lib()
     n = tt.numel(); dev = tt.device
     tt_sums = getattr(tt, "_gsx_block_sums", None)      # left by build_records on exactly this tensor, if any
     offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    total = torch.empty(1, dtype=torch.int64, device=dev)
+    if total is None:
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
     wsb = lib.gsx_scan_workspace_bytes(max(n, 1))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     pinned, ev = _scratch.count_slot(dev)
@@ -231,29 +239,45 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
     positions, scales, rotations, opacity, features = params
     n = positions.shape[0]
     mean2d, depth, cov2d, keys, pre = project(positions, scales, rotations, opacity, features, pose)
-    if order is None:
-        order = depth_order(keys)
-    rec, tt, rank_of = build_records(pre, order, H, W)
     # Binning and compositing are enqueued against the buffers' CAPACITY; the instance count D reaches the host
     # through pinned memory while the GPU is already sorting, so the stream never drains in the middle of a view
     # (gsx_bin_instances, the synchronising form, idles the GPU for ~0.1 ms per view).  If D exceeds the capacity
     # -- first view of a scene, or a sudden jump -- the truncated results are discarded and the tail is redone.
+    # The depth sort is optimistic in the same way: while the top byte of the depth keys is the same for every Gaussian
+    # (depths within a binade or two, as in an orbit around a scene) it sorts on 24 bits, three passes instead of four;
+    # the sort itself counts the keys that break the assumption, the count travels with D, and a view sorted on too few
+    # bits is redone on all 32.
     global _last_D
-    dev = rec.device
-    offsets, total, (pinned, ev) = bin_count(tt)
+    dev = pre.device
+    given_order = order
     while True:
+        total = torch.empty(2, dtype=torch.int64, device=dev)
+        bits = 32
+        if given_order is None:
+            bits = _scratch.depth_bits.get(dev, 32)
+            order = depth_order(keys, bits, total[1:])
+        rec, tt, rank_of = build_records(pre, order, H, W)
+        offsets, total, (pinned, ev) = bin_count(tt, total)
         cap = _scratch.cap(dev, n)
         tiles, ranks, ranges, chunk_base = bin_emit_sort(rec, offsets, total, n, H, W, cap)
         rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, cap,
                                                                               want_depth, need_bwd)
         ev.synchronize()
         D = int(pinned[0])
+        redo = False
+        if given_order is None:
+            constant_top = int(pinned[1]) == 0
+            _scratch.depth_bits[dev] = DEPTH_CHECK_BIT if constant_top else 32
+            redo = bits < 32 and not constant_top
         if D >= 0xFFFFFFFF:
             raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
-        if D <= cap:
+        if D > cap:
+            redo = True
+        if not redo:
             break
-        del tiles, ranks, ranges, chunk_base, rgb, alpha, dmap, state, chunk_state     # truncated results of the attempt
-        _scratch.grow(dev, D)
+        del tiles, ranks, ranges, chunk_base, rgb, alpha, dmap, state, chunk_state     # results of the failed attempt
+        if D > cap:
+            _scratch.grow(dev, D)
     _last_D = D
     vs = ViewState()
     vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, order, rank_of, rec, tt, offsets

@@ -55,12 +55,18 @@ int gsx_project_fwd(const float* positions, const float* scales, const float* ro
  * stable.  values_in == NULL means values are 0..n-1.  Result lands in keys_out/values_out;
  * keys_tmp/values_tmp are ping-pong buffers of n elements.  ws: gsx_sort_workspace_bytes(n).
  * Replaces torch.argsort (:198) [keys = depth_key, 32 bits] and is reused to order the
- * (tile, rank) instances by tile [keys = tile id]. */
+ * (tile, rank) instances by tile [keys = tile id].
+ * mismatch_dev (nullable, device u64): receives the number of keys whose bits [check_bit, 32) differ from keys_in[0]'s
+ * (0 for check_bit == 32).  A caller that sorted on fewer than 32 bits because the high bits were constant the last
+ * time (depth keys of a scene whose depths stay inside one binade or two: a quarter of the passes) reads it later to
+ * learn whether that still held, and sorts again on all bits if it did not; a full sort uses it to learn whether the
+ * next one may skip them. */
 size_t gsx_sort_workspace_bytes(int64_t n);
 int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_in,
                        uint32_t* keys_out, uint32_t* values_out,
                        uint32_t* keys_tmp, uint32_t* values_tmp,
-                       int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, void* stream);
+                       int64_t n, int begin_bit, int end_bit, int check_bit, uint64_t* mismatch_dev,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---- exclusive prefix sum of n u32; total (u64) written to *total_dev.  ws: gsx_scan_workspace_bytes(n). */
 size_t gsx_scan_workspace_bytes(int64_t n);
@@ -95,9 +101,10 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
                       uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
 /* The same binning in two asynchronous halves, for callers that must not stall the stream in the middle of a
  * forward (the synchronising read-back above idles the GPU for the length of a host round trip).
- * gsx_bin_count: offsets = exclusive scan of tiles_touched, *total_dev (device, u64) = instance count D;
- *   if D_pinned_host != NULL the count is also copied there asynchronously (pinned host memory; valid once the
- *   caller has synchronised on an event recorded after this call).  ws: gsx_scan_workspace_bytes(N).
+ * gsx_bin_count: offsets = exclusive scan of tiles_touched, total_dev[0] (device, u64) = instance count D;
+ *   total_dev has TWO u64: [1] belongs to the caller (the render path parks the depth sort's mismatch count there).
+ *   If D_pinned_host != NULL both words are also copied there asynchronously (16 bytes of pinned host memory; valid
+ *   once the caller has synchronised on an event recorded after this call).  ws: gsx_scan_workspace_bytes(N).
  *   tt_block_sums: from gsx_build_records (the scan is then one launch), or NULL.
  * gsx_bin_emit_sort: everything after the count, with D read from *total_dev ON THE DEVICE and clamped to
  *   `capacity` (which sizes the launches): no host synchronisation.  If D turns out to exceed capacity the

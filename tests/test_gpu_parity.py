@@ -106,13 +106,17 @@ def test_radix_sort_stable(dev, n, bits):
     k = torch.from_numpy(keys.view(np.int32)).to(dev); v = torch.from_numpy(vals.view(np.int32)).to(dev)
     ko, vo, kt, vt = (torch.empty_like(k) for _ in range(4))
     wsb = lib.gsx_sort_workspace_bytes(n); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    check_bit = 20 + (n % 9)
+    mism = torch.full((1,), -1, dtype=torch.int64, device=dev)
     L.check(lib.gsx_sort_pairs_u32(_ptr(k), _ptr(v), _ptr(ko), _ptr(vo), _ptr(kt), _ptr(vt), n, bits[0], bits[1],
-                                   _ptr(ws), wsb, _stream()), "sort")
+                                   check_bit, _ptr(mism), _ptr(ws), wsb, _stream()), "sort")
     torch.cuda.synchronize()
     digit = (keys >> np.uint32(bits[0])) & np.uint32((1 << (bits[1] - bits[0])) - 1)
     perm = np.argsort(digit, kind="stable")
     assert np.array_equal(_u32(ko), keys[perm])
     assert np.array_equal(_u32(vo), vals[perm])
+    # the count of keys whose bits [check_bit, 32) differ from the first key's (what lets a caller skip constant high bits)
+    assert int(mism.item()) == int(np.count_nonzero((keys >> np.uint32(check_bit)) != (keys[0] >> np.uint32(check_bit))))
 
 
 @pytest.mark.parametrize("n", [1, 255, 2048, 2049, 100003, 3_000_000])
@@ -259,7 +263,7 @@ def test_async_binning_matches_synchronous(dev, cap):
     offsets, total, (pinned, ev) = R.bin_count(t["tt"])
     tiles, ranks, ranges, chunk_base = R.bin_emit_sort(t["rec"], offsets, total, n, H, W, cap)
     torch.cuda.synchronize()
-    assert int(pinned[0]) == D and int(total.item()) == D
+    assert int(pinned[0]) == D and int(total[0].item()) == D
     assert np.array_equal(_u32(offsets)[:n], gp["offsets"])
     if cap >= D:
         assert np.array_equal(_u32(tiles)[:D], gp["tiles"]) and np.array_equal(_u32(ranks)[:D], gp["ranks"])
@@ -277,6 +281,31 @@ def test_async_binning_matches_synchronous(dev, cap):
     assert vs.D == D and R._scratch.cap(dev, n) >= D
     assert np.array_equal(outs[0].cpu().numpy(), gp["rgb"])
     R._scratch.capacity.pop(dev, None)
+
+
+def test_optimistic_depth_sort_recovers(dev, O):
+    """The render path sorts the depth keys on 24 bits while their top byte is constant (three radix passes instead of
+    four) and learns from the sort's own mismatch count, which travels with the instance count, whether that held.
+    Depths in [1.5, 2.5] straddle a binade whose keys differ in the top byte: a view sorted on 24 bits must be redone
+    on 32 and come out in the oracle's order; depths in [2.5, 3.5] keep the shortcut, with bit-identical results."""
+    from gaussian_splatting_amd import render as R
+    params = synth_scene(5000, 31, 0.004, 0.02)
+    P = tuple(torch.from_numpy(np.ascontiguousarray(params[k], np.float32)).to(dev) for k in PARAMS)
+    H, W = 64, 80
+    for tz, constant in ((1.0, False), (2.0, True)):
+        pose = pose_tz(tz); pose_t = torch.from_numpy(pose).to(dev)
+        fw = O.forward(params, pose, H, W, "tiled")
+        imgs = []
+        for hint in (24, 32):
+            R._scratch.depth_bits[dev] = hint
+            outs, vs, _ = R.forward_view(P, pose_t, H, W)
+            torch.cuda.synchronize()
+            assert np.array_equal(_u32(vs.order), fw["order"]), (tz, hint)
+            assert R._scratch.depth_bits[dev] == (24 if constant else 32), (tz, hint)
+            imgs.append(outs[0].cpu().numpy())
+        assert np.array_equal(imgs[0], imgs[1])
+        assert np.abs(imgs[0] - fw["rgb"]).max() < RGB_TOL
+    R._scratch.depth_bits.pop(dev, None)
 
 
 def test_occlusion_cut_backward(dev, O):
