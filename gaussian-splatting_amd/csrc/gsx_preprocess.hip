@@ -197,7 +197,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     uint32_t limit = (uint32_t)N;
     if (state) { const uint32_t s = state[0]; if (s != GSX_RANK_NONE && s + 1u < (uint32_t)N) limit = s + 1u; }
     uint32_t o0 = 0, tt = 0;
-    if (live && partials && r < limit) { o0 = offsets[r]; tt = tiles_touched[r]; }
+    // the splat's row count is the next offset minus its own (same 64-byte line 15 times in 16): one random gather, not two
+    if (live && partials && r < limit) { o0 = offsets[r]; tt = (r + 1u < (uint32_t)N) ? offsets[r + 1u] - o0 : tiles_touched[r]; }
     // rows of a splat: summed by its own lane in tile order when there are few; a splat with more than kRowsSolo rows
     // is summed by the whole wavefront (lane l takes rows l, l+64, ... in order, then a fixed butterfly): a
     // screen-sized splat would otherwise serialise thousands of loads in one lane.  Both orders are fixed, so the
