@@ -61,21 +61,22 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
     while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
-// also counts the tile's compositing chunks (GSX_CHUNK instances each); entry n_tiles is 0 so that
+// also counts the tile's compositing chunks (chunk_size_for(D) instances each); entry n_tiles is 0 so that
 // the exclusive scan of chunk_cnt[0..n_tiles] ends with the total
 __global__ __launch_bounds__(kBlock) void ranges_kernel(const uint32_t* __restrict__ tiles_sorted, const uint64_t* __restrict__ total_dev,
-                                                        uint32_t capacity, int n_tiles,
+                                                        uint32_t capacity, int n_tiles, int chunk_force,
                                                         uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_cnt)
 {
     const uint64_t total = *total_dev;
     const uint32_t D = total < capacity ? (uint32_t)total : capacity;
+    const uint32_t ch = chunk_size_for(D, chunk_force);
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t > n_tiles) return;
-    if (t == n_tiles) { chunk_cnt[t] = 0; return; }
+    if (t == n_tiles) { chunk_cnt[t] = 0; chunk_cnt[t + 1] = ch; return; }      // entry n_tiles + 1 (outside the scan): the chunk size
     const uint32_t lb = lower_bound_u32(tiles_sorted, D, (uint32_t)t);
     const uint32_t ub = lower_bound_u32(tiles_sorted, D, (uint32_t)t + 1u);
     ranges[2*t] = lb; ranges[2*t+1] = ub;
-    chunk_cnt[t] = (ub - lb + GSX_CHUNK - 1) / GSX_CHUNK;
+    chunk_cnt[t] = (ub - lb + ch - 1) / ch;
 }
 
 static int tile_bits(int n_tiles) { int b = 1; while ((1 << b) < n_tiles) b++; return b; }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                   const uint64_t* __restrict__ total_dev, int64_t capacity, int n_tiles,
                                                                   const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
-                                                                  uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base)
+                                                                  int chunk_force, uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base)
 {
     __shared__ uint16_t s_cnt[kTsWaves][kTsDigits];      // per-wave digit counts, then per-wave offsets inside the workgroup
     __shared__ uint32_t s_base[kTsDigits];               // per tile: global slot minus position inside the workgroup
@@ -220,19 +221,20 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
     const uint32_t ex = block1024_excl_scan((tv[0] + tv[1]) + (tv[2] + tv[3]), s_scan, &tot);
     db[0] = ex; db[1] = db[0] + tv[0]; db[2] = db[1] + tv[1]; db[3] = db[2] + tv[2];
     if (blockIdx.x == 0) {
-        // what ranges_kernel and the chunk-table scan did: ranges[t] = [first, last), chunk_base = scan of ceil(len / GSX_CHUNK)
+        // what ranges_kernel and the chunk-table scan did: ranges[t] = [first, last), chunk_base = scan of ceil(len / chunk size)
+        const uint32_t ch = chunk_size_for((uint64_t)n, chunk_force);
         uint32_t cc[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int d = 4 * tid + i;
-            cc[i] = d < n_tiles ? (tv[i] + GSX_CHUNK - 1) / GSX_CHUNK : 0u;
+            cc[i] = d < n_tiles ? (tv[i] + ch - 1) / ch : 0u;
             if (d < n_tiles) { ranges[2 * d] = db[i]; ranges[2 * d + 1] = db[i] + tv[i]; }
         }
         uint32_t ctot;
         uint32_t cex = block1024_excl_scan((cc[0] + cc[1]) + (cc[2] + cc[3]), s_scan, &ctot);
 #pragma unroll
         for (int i = 0; i < 4; i++) { const int d = 4 * tid + i; if (d < n_tiles) chunk_base[d] = cex; cex += cc[i]; }
-        if (tid == 0) chunk_base[n_tiles] = ctot;
+        if (tid == 0) { chunk_base[n_tiles] = ctot; chunk_base[n_tiles + 1] = ch; }
         if (!active) return;
     }
     const uint32_t* prow = hist_scanned + (size_t)blockIdx.x * kTsDigits;
@@ -338,10 +340,18 @@ GSX_API size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity)
     return 256 + (m > c ? m : c);
 }
 
-GSX_API int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W)
+GSX_API int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W, int32_t chunk_force)
 {
     const int64_t n_tiles = (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE);
-    return D / GSX_CHUNK + (D < n_tiles ? D : n_tiles);
+    if (D < 0) D = 0;
+    // the largest chunk count any instance count <= D can produce: the device shortens the chunks of small views
+    int64_t full;
+    if (chunk_force == 64 || chunk_force == 128 || chunk_force == 256) full = D / chunk_force;
+    else {
+        const int64_t a = (D < (1ll << 19) ? D : (1ll << 19) - 1) / 64, b = (D < (1ll << 20) ? D : (1ll << 20) - 1) / 128, c = D / GSX_CHUNK;
+        full = a > b ? a : b; if (c > full) full = c;
+    }
+    return full + (D < n_tiles ? D : n_tiles);
 }
 
 GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, int32_t N, uint32_t* offsets, uint64_t* total_dev,
@@ -359,9 +369,10 @@ GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_bloc
 GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                               int64_t capacity, const uint64_t* total_dev,
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                              uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream)
+                              uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity <= 0) return GSX_E_INVALID;
+    if (chunk_force != 0 && chunk_force != 64 && chunk_force != 128 && chunk_force != 256) return GSX_E_INVALID;
     if (capacity >= 0xFFFFFFFFll) return GSX_E_RANGE;
     if (!ranges || !chunk_base || !total_dev || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
     if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
@@ -386,7 +397,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
         }
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
         tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
-                                                                    hist, totals, ranges, chunk_base);
+                                                                    hist, totals, chunk_force, ranges, chunk_base);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }
@@ -400,7 +411,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
         int s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, capacity, total_dev, 0, bits, sub_ws, sub_bytes, st);
         if (s != GSX_OK) return s;
     }
-    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, total_dev, (uint32_t)capacity, n_tiles, ranges, chunk_base);
+    ranges_kernel<<<dim3((unsigned)ceil_div(n_tiles + 1, kBlock)), dim3(kBlock), 0, st>>>(tiles_sorted, total_dev, (uint32_t)capacity, n_tiles, chunk_force, ranges, chunk_base);
     GSX_LAUNCH_CHECK();
     return scan_internal(chunk_base, chunk_base, nullptr, (int64_t)n_tiles + 1, sub_ws, sub_bytes, st);
 }
@@ -408,7 +419,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
 GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
                               int64_t capacity, uint32_t* offsets,
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                              uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream)
+                              uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, int64_t* D_host, void* ws, size_t ws_bytes, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity < 0) return GSX_E_INVALID;
     if (!ranges || !chunk_base || !D_host || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
@@ -418,6 +429,7 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     auto empty = [&]() -> int {
         GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 8, st));
         GSX_HIP(hipMemsetAsync(chunk_base, 0, (size_t)(n_tiles + 1) * 4, st));
+        GSX_HIP(hipMemsetD32Async((hipDeviceptr_t)(chunk_base + n_tiles + 1), (int)chunk_size_for(0, chunk_force), 1, st));
         return GSX_OK;
     };
     if (N == 0) return empty();
@@ -434,5 +446,5 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     if ((int64_t)D > capacity) return GSX_E_CAPACITY;
     if (D == 0) return empty();
     return gsx_bin_emit_sort(rec, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
-                             ranges, chunk_base, ws, ws_bytes, stream);
+                             ranges, chunk_base, chunk_force, ws, ws_bytes, stream);
 }

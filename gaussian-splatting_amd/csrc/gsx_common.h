@@ -25,6 +25,16 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 constexpr int kBlock = 256;        // 4 wave64
 constexpr int kWave = 64;
 
+// Instances per compositing chunk for a view of D instances (gsx_constants.h): one wave composites one chunk, so a small
+// view cut into 256-instance chunks is a few hundred waves on 4096 wave slots, each running its 256 splats alone -- the
+// kernels then take one chunk's latency whatever the size of the scene.  Shorter chunks for smaller views; the choice is
+// a function of D alone, made on the device, and written behind the chunk table for the compositing kernels.
+__host__ __device__ inline uint32_t chunk_size_for(uint64_t D, int force)
+{
+    if (force == 64 || force == 128 || force == 256) return (uint32_t)force;
+    return D < (1ull << 19) ? 64u : D < (1ull << 20) ? 128u : (uint32_t)GSX_CHUNK;
+}
+
 // -0.5 * log2(e): conic pre-multiplier so that alpha = o * exp2(q')
 #define GSX_NEG_HALF_LOG2E (-0.72134752f)
 #define GSX_LN2 0.69314718f

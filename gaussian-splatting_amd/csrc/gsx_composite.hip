@@ -139,16 +139,18 @@ __device__ __forceinline__ uint32_t chunk_of_block(uint32_t block, uint32_t tota
 
 struct ChunkGeom { int tile, tx, ty; uint32_t begin, end; };
 
-// chunk -> (tile, instance range).  chunk_base has n_tiles+1 entries (exclusive scan of chunks per tile).
+// chunk -> (tile, instance range).  chunk_base has n_tiles+2 entries: the exclusive scan of chunks per tile (n_tiles + 1)
+// and, last, the chunk size the binning stage chose for this view (64, 128 or 256 instances: chunk_size_for).
 __device__ __forceinline__ ChunkGeom chunk_locate(const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t chunk,
                                                   const uint32_t* __restrict__ ranges, int tw)
 {
+    const uint32_t ch = chunk_base[n_tiles + 1];
     int lo = 0, hi = n_tiles - 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (chunk_base[mid + 1] > chunk) hi = mid; else lo = mid + 1; }
     ChunkGeom g;
     g.tile = lo; g.tx = lo % tw; g.ty = lo / tw;
-    g.begin = ranges[2*lo] + (chunk - chunk_base[lo]) * (uint32_t)GSX_CHUNK;
-    g.end = min(g.begin + (uint32_t)GSX_CHUNK, ranges[2*lo+1]);
+    g.begin = ranges[2*lo] + (chunk - chunk_base[lo]) * ch;
+    g.end = min(g.begin + ch, ranges[2*lo+1]);
     return g;
 }
 
@@ -338,8 +340,9 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                 if (valid) {
                     const uint32_t meta = chunk_meta[c];
                     const uint32_t n_dark = (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]);
-                    const uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * GSX_CHUNK
-                    cls = n_dark == 4u ? 4 : est >= 10u * GSX_CHUNK ? 0 : est >= 6u * GSX_CHUNK ? 1 : est >= 3u * GSX_CHUNK ? 2 : 3;
+                    const uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * chunk size
+                    const uint32_t ch = chunk_base[gridDim.x + 1];                                                  // gridDim.x == n_tiles
+                    cls = n_dark == 4u ? 4 : est >= 10u * ch ? 0 : est >= 6u * ch ? 1 : est >= 3u * ch ? 2 : 3;
                 }
                 const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
                 uint32_t* cnt = work_counters(work, PASS1);

@@ -67,6 +67,7 @@ class _Scratch:
         self.capacity = {}
         self.pinned = {}
         self.depth_bits = {}      # per device: key bits the next depth sort covers (24 while the top byte is constant)
+        self.force_chunk = 0      # 64 / 128 / 256 pins the compositing chunk size (tests); 0 = the device picks it from D
 
     def cap(self, dev, n):
         return self.capacity.get(dev, max(4 * n, 1 << 16))
@@ -144,7 +145,7 @@ def bin_instances(rec, tt, H, W):
     tw, th = (W + L.TILE - 1) // L.TILE, (H + L.TILE - 1) // L.TILE
     offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     ranges = torch.empty(tw * th, 2, dtype=torch.int32, device=dev)
-    chunk_base = torch.empty(tw * th + 1, dtype=torch.int32, device=dev)
+    chunk_base = torch.empty(tw * th + 2, dtype=torch.int32, device=dev)      # + the chunk size the device picked
     D = C.c_int64(0)
     for _attempt in range(2):
         cap = _scratch.cap(dev, n)
@@ -153,7 +154,7 @@ def bin_instances(rec, tt, H, W):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         with _stage("bin_instances"):
             st = lib.gsx_bin_instances(_ptr(rec), _ptr(tt), n, H, W, cap, _ptr(offsets), _ptr(bufs[0]), _ptr(bufs[1]),
-                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), C.byref(D), _ptr(ws), wsb, _stream())
+                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), _scratch.force_chunk, C.byref(D), _ptr(ws), wsb, _stream())
         if st == L.GSX_E_CAPACITY:
             _scratch.grow(dev, D.value)
             continue
@@ -193,13 +194,13 @@ def bin_emit_sort(rec, offsets, total, n, H, W, cap):
     dev = rec.device
     tw, th = (W + L.TILE - 1) // L.TILE, (H + L.TILE - 1) // L.TILE
     ranges = torch.empty(tw * th, 2, dtype=torch.int32, device=dev)
-    chunk_base = torch.empty(tw * th + 1, dtype=torch.int32, device=dev)
+    chunk_base = torch.empty(tw * th + 2, dtype=torch.int32, device=dev)      # + the chunk size the device picked
     bufs = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
     wsb = lib.gsx_bin_workspace_bytes(n, cap)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     with _stage("bin_emit_sort"):
         L.check(lib.gsx_bin_emit_sort(_ptr(rec), _ptr(offsets), n, H, W, cap, _ptr(total), _ptr(bufs[0]), _ptr(bufs[1]),
-                                      _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), _ptr(ws), wsb, _stream()),
+                                      _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), _scratch.force_chunk, _ptr(ws), wsb, _stream()),
                 "gsx_bin_emit_sort")
     return bufs[0], bufs[1], ranges, chunk_base
 
@@ -219,7 +220,7 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
     alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
     state = torch.empty(4, dtype=torch.int32, device=dev)
-    max_chunks = int(lib.gsx_max_chunks(D, H, W))
+    max_chunks = int(lib.gsx_max_chunks(D, H, W, _scratch.force_chunk))
     chunk_state = torch.empty(max(max_chunks, 1) * (L.STATE_WORDS * 256 + 12) + 16, dtype=torch.float32, device=dev)
     with _stage("composite_fwd"):
         L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), _ptr(chunk_base), n, H, W,

@@ -91,14 +91,17 @@ int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_
  *   tiles_sorted / ranks_sorted : results (D valid elements)
  *   tiles_tmp / ranks_tmp       : scratch of the same capacity
  *   ranges       : n_tiles x 2 u32, ranges[t] = [lower_bound(t), lower_bound(t+1)) into the sorted arrays
- *   chunk_base   : n_tiles + 1 u32, exclusive scan of ceil(len(t) / GSX_CHUNK); last entry = chunk count
+ *   chunk_base   : n_tiles + 2 u32: exclusive scan of ceil(len(t) / chunk) (entry n_tiles = chunk count), then the chunk
+ *                  size itself (64 for D < 2^19, 128 for D < 2^20, else GSX_CHUNK = 256: a small view cut into long chunks
+ *                  would leave most of the chip idle); chunk_force = 64 / 128 / 256 overrides the choice, 0 = automatic
  *   *D_host      : instance count (also on GSX_E_CAPACITY, so the caller can grow and retry)
  * ws: gsx_bin_workspace_bytes(N, capacity). */
 size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity);
 int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N, int32_t H, int32_t W,
                       int64_t capacity, uint32_t* offsets,
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                      uint32_t* ranges, uint32_t* chunk_base, int64_t* D_host, void* ws, size_t ws_bytes, void* stream);
+                      uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, int64_t* D_host,
+                      void* ws, size_t ws_bytes, void* stream);
 /* The same binning in two asynchronous halves, for callers that must not stall the stream in the middle of a
  * forward (the synchronising read-back above idles the GPU for the length of a host round trip).
  * gsx_bin_count: offsets = exclusive scan of tiles_touched, total_dev[0] (device, u64) = instance count D;
@@ -116,11 +119,12 @@ int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, 
 int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                       int64_t capacity, const uint64_t* total_dev,
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                      uint32_t* ranges, uint32_t* chunk_base, void* ws, size_t ws_bytes, void* stream);
-/* upper bound on the chunk count for D instances: D / GSX_CHUNK + min(D, n_tiles).  The caller sizes
+                      uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream);
+/* upper bound on the chunk count of any view of at most D instances (max over the chunk sizes the device may pick, or
+ * D / chunk_force) + min(D, n_tiles).  The caller sizes
  * chunk_state with it: GSX_CHUNK_STATE_FLOATS(max_chunks) floats (the tail holds the per-chunk
  * meta words and the backward work lists, gsx_constants.h). */
-int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W);
+int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W, int32_t chunk_force);
 
 /* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  A tile's depth-ordered
  * list is cut into chunks of GSX_CHUNK instances; one wave64 composites one chunk for the whole

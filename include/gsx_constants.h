@@ -35,7 +35,10 @@
 
 /* compositing work item: at most GSX_CHUNK consecutive instances of one tile's depth-ordered list,
  * composited by one wave64 (4 pixels per lane); chunk results are combined per tile afterwards
- * (alpha compositing is associative), so the load is balanced however the splats fall on screen */
+ * (alpha compositing is associative), so the load is balanced however the splats fall on screen.
+ * GSX_CHUNK is the LARGEST chunk: the binning stage cuts views of fewer than 2^20 instances into chunks of 128 and of
+ * fewer than 2^19 into chunks of 64 (more, shorter work items: a small view is otherwise a few hundred waves on 4096
+ * wave slots) and stores the size it used in chunk_base[n_tiles + 1] */
 #define GSX_CHUNK 256
 /* floats per pixel per chunk in the chunk-state buffer:
  *  0..2 local colour (later: colour behind the chunk)  3,4 local transmittance (mantissa, exponent)

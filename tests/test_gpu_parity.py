@@ -55,8 +55,10 @@ def gpu_pipeline(params, pose, H, W, dev, order=None):
                n_composited=(s + 1 if (s != 0xFFFFFFFF and s + 1 < n) else n))
     cb = _u32(chunk_base)
     lens = (out["ranges"][:, 1] - out["ranges"][:, 0]).astype(np.int64)
-    assert np.array_equal(cb, np.concatenate([[0], np.cumsum((lens + L_CHUNK - 1) // L_CHUNK)]).astype(np.uint32)), "chunk table"
-    assert int(cb[-1]) <= max_chunks
+    ch = int(cb[-1])                                   # the chunk size the device picked: a function of D alone
+    assert ch == (R._scratch.force_chunk or (64 if D < (1 << 19) else 128 if D < (1 << 20) else L_CHUNK))
+    assert np.array_equal(cb[:-1], np.concatenate([[0], np.cumsum((lens + ch - 1) // ch)]).astype(np.uint32)), "chunk table"
+    assert int(cb[-2]) <= max_chunks
     out["_t"] = dict(P=P, pose=pose_t, order=order_t, rank_of=rank_of, rec=rec, tt=tt, offsets=offsets, ranks=ranks, ranges=ranges,
                      chunk_base=chunk_base, chunk_state=chunk_state, max_chunks=max_chunks, state=state, D=D)
     return out
@@ -218,6 +220,28 @@ def test_synthetic_vs_oracle(dev, O, case):
         assert rel_err(g[k], go[k]) < tol, k + " (rgb only)"
 
 
+@pytest.mark.parametrize("chunk", [64, 128, 256])
+def test_every_chunk_size_vs_oracle(dev, O, chunk):
+    """The binning stage cuts small views into shorter compositing chunks (64 / 128 / 256 instances by instance count);
+    each size against the oracle on the same scene, forward and backward (the automatic choice is covered by every
+    other test: small scenes get 64, the full-size test 256)."""
+    from gaussian_splatting_amd import render as R
+    params, pose, H, W = CASES["c2_20000_256x256"]()
+    R._scratch.force_chunk = chunk
+    try:
+        gp = gpu_pipeline(params, pose, H, W, dev)
+        fw = O.forward(params, pose, H, W, "tiled")
+        assert_integer_products_equal(gp, fw)
+        assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
+        d_rgb = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
+        g = gpu_backward(gp, H, W, d_rgb)
+        go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
+        for k in PARAMS:
+            assert rel_err(g[k], go[k]) < GRAD_RTOL, k
+    finally:
+        R._scratch.force_chunk = 0
+
+
 def test_module_dropin_matches_reference_outputs(dev):
     """GaussianSplat(nn.Module): same state_dict keys, same output dict, autograd through all
     three gradient routes (rendered_images, scales, opacity: SURVEY fact 8)."""
@@ -323,7 +347,7 @@ def test_occlusion_cut_backward(dev, O):
     assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
     # the cut must actually fire here: chunks whose predecessor ends with every pixel's exponent <= -24
     t = gp["_t"]
-    cb = _u32(t["chunk_base"]).astype(np.int64); nch = int(cb[-1])
+    cb = _u32(t["chunk_base"]).astype(np.int64)[:-1]; nch = int(cb[-1])      # (the last entry of the buffer is the chunk size)
     st = t["chunk_state"][: nch * 8 * 256].view(nch, 8, 256).cpu().numpy()
     e_end = st[:, 7, :].view(np.int32); m_end = st[:, 6, :]
     dark_end = np.all((m_end == 0) | (e_end <= -24), axis=1)

@@ -26,7 +26,10 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.gsx_strerror(-2).decode().startswith("instance buffers")
     # pure host helpers (no GPU): workspace sizes and the chunk bound
     assert lib.gsx_sort_workspace_bytes(1 << 20) >= 256 * 256 * 4
-    assert lib.gsx_max_chunks(1000, 64, 64) == 1000 // 256 + 16
+    assert lib.gsx_max_chunks(1000, 64, 64, 256) == 1000 // 256 + 16
+    assert lib.gsx_max_chunks(1000, 64, 64, 0) == 1000 // 64 + 16                         # small views get 64-instance chunks
+    assert lib.gsx_max_chunks(3 << 20, 64, 64, 0) == (3 << 20) // 256 + 16                # large ones 256 ...
+    assert lib.gsx_max_chunks((1 << 20) + 5, 64, 64, 0) == ((1 << 19) - 1) // 64 + 16      # ... but a smaller count may need more chunks
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (gsx_[a-z0-9_]+)", nm)))
     assert exported == declared, "the library must export exactly the declared C ABI"
