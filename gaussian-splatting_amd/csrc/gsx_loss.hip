@@ -100,14 +100,94 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
 // metric, /root/reference/model/evaluation.py:97-105), so this follows the usual splatting formulation: per-channel
 // 11x11 Gaussian window (sigma 1.5, zero padding), C1 = 0.01^2, C2 = 0.03^2.  Parity unpinned by the reference;
 // tested against a torch fp32 restatement (conv2d + autograd).
-// One workgroup per 16x16 output tile of one image plane: 26x26 halo of both images in LDS, separable window
-// (11 + 11 taps instead of 121) on five moments, SSIM and its three partial derivatives in registers; the backward
+// One workgroup per 32x32 output tile of one image plane: 42x42 halo of both images in LDS, separable window
+// (11 + 11 taps instead of 121; each thread filters 4 adjacent outputs, which share most of their taps' loads) on five moments, SSIM and its three partial derivatives in registers; the backward
 // is a second separable pass over those three derivative maps.  torch spends ~40 launches and 15 image-sized
 // temporaries on the pair; this is 3 launches, 8 B/px-channel read + 12 B written forward, 20 B read + 4 B written backward.
 // ------------------------------------------------------------------------------------------
-constexpr int kSsimTaps = 11, kSsimHalf = 5, kSsimTile = 16, kSsimHalo = kSsimTile + 2 * kSsimHalf;   // 26
+constexpr int kSsimTaps = 11, kSsimHalf = 5, kSsimTile = 32, kSsimHalo = kSsimTile + 2 * kSsimHalf;   // 32x32 outputs, 42x42 inputs
+constexpr int kSsimRun = 4;                                  // outputs per thread along the filtered axis (they share 14 of 44 taps' loads)
 constexpr float kSsimC1 = 0.01f * 0.01f, kSsimC2 = 0.03f * 0.03f;
 struct SsimWindow { float g[kSsimTaps]; };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float a) { f32x2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32: two FMAs per issue slot
+
+// One filtered run: 4 adjacent outputs (two packed pairs) from 14 inputs; pair p covers outputs 2p, 2p+1, whose tap for
+// input j is g[j - 2p] and g[j - 2p - 1] (zero outside 0..10).  The kernels are VALU-issue bound (1170 wave instructions
+// per wave before packing, 53 % of the issue slots used), so the taps go through the packed-fp32 pipe.
+struct SsimTaps { f32x2 w[kSsimTaps + kSsimRun - 1][kSsimRun / 2]; };
+__device__ __forceinline__ SsimTaps ssim_taps(const SsimWindow& win)
+{
+    SsimTaps t;
+#pragma unroll
+    for (int j = 0; j < kSsimTaps + kSsimRun - 1; j++)
+#pragma unroll
+        for (int p = 0; p < kSsimRun / 2; p++) {
+            const int k0 = j - 2 * p, k1 = j - 2 * p - 1;
+            t.w[j][p].x = (k0 >= 0 && k0 < kSsimTaps) ? win.g[k0] : 0.0f;
+            t.w[j][p].y = (k1 >= 0 && k1 < kSsimTaps) ? win.g[k1] : 0.0f;
+        }
+    return t;
+}
+
+// horizontal pass over NQ row-major [kSsimHalo][kSsimHalo + 1] planes: out[q][r][c] = sum_k g[k] * f_q(r, c + k), c < kSsimTile;
+// one work item = 4 adjacent outputs of one row.  f(vals, r, c) returns the NQ values at input column c.
+template <int NQ, typename F>
+__device__ __forceinline__ void ssim_rows(const SsimTaps& T, float (*out)[kSsimHalo][kSsimTile], F f)
+{
+    constexpr int kItems = kSsimHalo * (kSsimTile / kSsimRun);
+    for (int it = threadIdx.x; it < kItems; it += kBlock) {
+        const int r = it / (kSsimTile / kSsimRun), c0 = (it - r * (kSsimTile / kSsimRun)) * kSsimRun;
+        f32x2 acc[NQ][kSsimRun / 2];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int p = 0; p < kSsimRun / 2; p++) acc[q][p] = splat2(0.0f);
+#pragma unroll
+        for (int j = 0; j < kSsimTaps + kSsimRun - 1; j++) {
+            float v[NQ];
+            f(v, r, c0 + j);
+#pragma unroll
+            for (int p = 0; p < kSsimRun / 2; p++) {
+                if (j - 2 * p >= 0 && j - 2 * p - 1 < kSsimTaps) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acc[q][p] = pk_fma(T.w[j][p], splat2(v[q]), acc[q][p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int p = 0; p < kSsimRun / 2; p++) { out[q][r][c0 + 2 * p] = acc[q][p].x; out[q][r][c0 + 2 * p + 1] = acc[q][p].y; }
+    }
+}
+
+// vertical pass: thread (c = tid % 32, rows 4 * (tid / 32) .. + 3); res[q][o] = sum_k g[k] * in[q][r0 + o + k][c]
+template <int NQ>
+__device__ __forceinline__ void ssim_cols(const SsimTaps& T, const float (*in)[kSsimHalo][kSsimTile], int r0, int c, float (*res)[kSsimRun])
+{
+    f32x2 acc[NQ][kSsimRun / 2];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int p = 0; p < kSsimRun / 2; p++) acc[q][p] = splat2(0.0f);
+#pragma unroll
+    for (int j = 0; j < kSsimTaps + kSsimRun - 1; j++) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float v = in[q][r0 + j][c];
+#pragma unroll
+            for (int p = 0; p < kSsimRun / 2; p++)
+                if (j - 2 * p >= 0 && j - 2 * p - 1 < kSsimTaps) acc[q][p] = pk_fma(T.w[j][p], splat2(v), acc[q][p]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int p = 0; p < kSsimRun / 2; p++) { res[q][2 * p] = acc[q][p].x; res[q][2 * p + 1] = acc[q][p].y; }
+}
 
 __global__ __launch_bounds__(kBlock) void ssim_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int H, int W,
                                                           SsimWindow win, float* __restrict__ maps, long long map_stride,
@@ -121,54 +201,63 @@ __global__ __launch_bounds__(kBlock) void ssim_fwd_kernel(const float* __restric
     const long long plane = (long long)blockIdx.z * H * W;
     const float* px = pred + plane;
     const float* py = target + plane;
-    for (int i = tid; i < kSsimHalo * kSsimHalo; i += kBlock) {
-        const int r = i / kSsimHalo, c = i - r * kSsimHalo;
-        const int gy = y0 + r - kSsimHalf, gx = x0 + c - kSsimHalf;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        s_x[r][c] = in ? px[(long long)gy * W + gx] : 0.0f;
-        s_y[r][c] = in ? py[(long long)gy * W + gx] : 0.0f;
+    {
+        // all of the thread's halo loads are issued before the first LDS store: written as one loop the compiler waits for
+        // each pair of loads in turn, and seven dependent HBM latencies were most of this kernel's time
+        constexpr int kIters = (kSsimHalo * kSsimHalo + kBlock - 1) / kBlock;
+        float vx[kIters], vy[kIters];
+#pragma unroll
+        for (int u = 0; u < kIters; u++) {
+            const int i = tid + u * kBlock;
+            const int r = i / kSsimHalo, c = i - r * kSsimHalo;
+            const int gy = y0 + r - kSsimHalf, gx = x0 + c - kSsimHalf;
+            const bool in = i < kSsimHalo * kSsimHalo && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            vx[u] = in ? px[(long long)gy * W + gx] : 0.0f;
+            vy[u] = in ? py[(long long)gy * W + gx] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kIters; u++) {
+            const int i = tid + u * kBlock;
+            if (i < kSsimHalo * kSsimHalo) { const int r = i / kSsimHalo, c = i - r * kSsimHalo; s_x[r][c] = vx[u]; s_y[r][c] = vy[u]; }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < kSsimHalo * kSsimTile; i += kBlock) {
-        const int r = i / kSsimTile, c = i - r * kSsimTile;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kSsimTaps; k++) {
-            const float w = win.g[k], xv = s_x[r][c + k], yv = s_y[r][c + k];
-            a0 += w * xv; a1 += w * yv; a2 += w * (xv * xv); a3 += w * (yv * yv); a4 += w * (xv * yv);
-        }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
-    }
+    const SsimTaps T = ssim_taps(win);
+    ssim_rows<5>(T, s_h, [&](float* v, int r, int c) {
+        const float xv = s_x[r][c], yv = s_y[r][c];
+        v[0] = xv; v[1] = yv; v[2] = xv * xv; v[3] = yv * yv; v[4] = xv * yv;
+    });
     __syncthreads();
-    const int r = tid / kSsimTile, c = tid - r * kSsimTile;
-    const int gy = y0 + r, gx = x0 + c;
-    float ssim = 0.0f, l1 = 0.0f;
-    if (gy < H && gx < W) {
-        float mu1 = 0.0f, mu2 = 0.0f, s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
+    const int c = tid & (kSsimTile - 1), r0 = (tid / kSsimTile) * kSsimRun;
+    float mom[5][kSsimRun];
+    ssim_cols<5>(T, s_h, r0, c, mom);
+    float ssim_sum = 0.0f, l1_sum = 0.0f;
+    const int gx = x0 + c;
 #pragma unroll
-        for (int k = 0; k < kSsimTaps; k++) {
-            const float w = win.g[k];
-            mu1 += w * s_h[0][r + k][c]; mu2 += w * s_h[1][r + k][c];
-            s11 += w * s_h[2][r + k][c]; s22 += w * s_h[3][r + k][c]; s12 += w * s_h[4][r + k][c];
-        }
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float A = 2.0f * mu12 + kSsimC1;
-        const float B = 2.0f * (s12 - mu12) + kSsimC2;
-        const float Cc = mu1_sq + mu2_sq + kSsimC1;
-        const float D = (s11 - mu1_sq) + (s22 - mu2_sq) + kSsimC2;
-        const float inv_cd = 1.0f / (Cc * D);
-        ssim = A * B * inv_cd;
-        const float xv = s_x[r + kSsimHalf][c + kSsimHalf], yv = s_y[r + kSsimHalf][c + kSsimHalf];
-        l1 = fabsf(xv - yv);
-        if (maps) {
-            // d ssim / d mu1 (with the second moments held fixed), d ssim / d E[x^2], d ssim / d E[xy]
-            const long long o = plane + (long long)gy * W + gx;
-            maps[o] = 2.0f * mu2 * (B - A) * inv_cd - 2.0f * mu1 * ssim * (1.0f / Cc - 1.0f / D);
-            maps[o + map_stride] = -ssim / D;
-            maps[o + 2 * map_stride] = 2.0f * A * inv_cd;
+    for (int o = 0; o < kSsimRun; o++) {
+        const int gy = y0 + r0 + o;
+        if (gy < H && gx < W) {
+            const float mu1 = mom[0][o], mu2 = mom[1][o], s11 = mom[2][o], s22 = mom[3][o], s12 = mom[4][o];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float A = 2.0f * mu12 + kSsimC1;
+            const float B = 2.0f * (s12 - mu12) + kSsimC2;
+            const float Cc = mu1_sq + mu2_sq + kSsimC1;
+            const float D = (s11 - mu1_sq) + (s22 - mu2_sq) + kSsimC2;
+            const float rc = __builtin_amdgcn_rcpf(Cc), rd = __builtin_amdgcn_rcpf(D);      // 1 ulp; four IEEE divisions were 15 % of the kernel's instructions
+            const float inv_cd = rc * rd;
+            const float ssim = A * B * inv_cd;
+            ssim_sum += ssim;
+            l1_sum += fabsf(s_x[r0 + o + kSsimHalf][c + kSsimHalf] - s_y[r0 + o + kSsimHalf][c + kSsimHalf]);
+            if (maps) {
+                // d ssim / d mu1 (with the second moments held fixed), d ssim / d E[x^2], d ssim / d E[xy]
+                const long long oo = plane + (long long)gy * W + gx;
+                maps[oo] = 2.0f * mu2 * (B - A) * inv_cd - 2.0f * mu1 * ssim * (rc - rd);
+                maps[oo + map_stride] = -ssim * rd;
+                maps[oo + 2 * map_stride] = 2.0f * A * inv_cd;
+            }
         }
     }
-    double sd = (double)ssim, ld = (double)l1;
+    double sd = (double)ssim_sum, ld = (double)l1_sum;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sd += __shfl_down(sd, d, 64); ld += __shfl_down(ld, d, 64); }
     if ((tid & 63) == 0) { s_red[0][tid >> 6] = sd; s_red[1][tid >> 6] = ld; }
@@ -181,15 +270,17 @@ __global__ __launch_bounds__(kBlock) void ssim_fwd_kernel(const float* __restric
 }
 
 // loss[0] = (1 - lambda) * l1 + lambda * (1 - ssim), loss[1] = mean |x - y|, loss[2] = mean ssim
-__global__ __launch_bounds__(kBlock) void ssim_final_kernel(const double* __restrict__ partials, long long nblocks, long long n, float lambda,
-                                                            float* __restrict__ loss)
+constexpr int kSsimFinalThreads = 1024;
+__global__ __launch_bounds__(kSsimFinalThreads) void ssim_final_kernel(const double* __restrict__ partials, long long nblocks, long long n, float lambda,
+                                                                       float* __restrict__ loss)
 {
-    __shared__ double s_v[2][kBlock];
+    __shared__ double s_v[2][kSsimFinalThreads];
+    const double2* p2 = reinterpret_cast<const double2*>(partials);
     double s = 0.0, l = 0.0;
-    for (long long i = threadIdx.x; i < nblocks; i += kBlock) { s += partials[2 * i]; l += partials[2 * i + 1]; }
+    for (long long i = threadIdx.x; i < nblocks; i += kSsimFinalThreads) { const double2 v = p2[i]; s += v.x; l += v.y; }
     s_v[0][threadIdx.x] = s; s_v[1][threadIdx.x] = l;
     __syncthreads();
-    for (int d = kBlock / 2; d > 0; d >>= 1) {
+    for (int d = kSsimFinalThreads / 2; d > 0; d >>= 1) {
         if (threadIdx.x < d) { s_v[0][threadIdx.x] += s_v[0][threadIdx.x + d]; s_v[1][threadIdx.x] += s_v[1][threadIdx.x + d]; }
         __syncthreads();
     }
@@ -210,42 +301,46 @@ __global__ __launch_bounds__(kBlock) void ssim_bwd_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kSsimTile, y0 = blockIdx.y * kSsimTile;
     const long long plane = (long long)blockIdx.z * H * W;
-    for (int i = tid; i < kSsimHalo * kSsimHalo; i += kBlock) {
-        const int r = i / kSsimHalo, c = i - r * kSsimHalo;
-        const int gy = y0 + r - kSsimHalf, gx = x0 + c - kSsimHalf;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;     // no window is centred outside the image
-        const long long o = plane + (long long)gy * W + gx;
-        s_m[0][r][c] = in ? maps[o] : 0.0f;
-        s_m[1][r][c] = in ? maps[o + map_stride] : 0.0f;
-        s_m[2][r][c] = in ? maps[o + 2 * map_stride] : 0.0f;
-    }
-    __syncthreads();
-    for (int i = tid; i < kSsimHalo * kSsimTile; i += kBlock) {
-        const int r = i / kSsimTile, c = i - r * kSsimTile;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    {
+        constexpr int kIters = (kSsimHalo * kSsimHalo + kBlock - 1) / kBlock;      // loads first, LDS stores after (see the forward)
+        float v0[kIters], v1[kIters], v2[kIters];
 #pragma unroll
-        for (int k = 0; k < kSsimTaps; k++) {
-            const float w = win.g[k];
-            a0 += w * s_m[0][r][c + k]; a1 += w * s_m[1][r][c + k]; a2 += w * s_m[2][r][c + k];
+        for (int u = 0; u < kIters; u++) {
+            const int i = tid + u * kBlock;
+            const int r = i / kSsimHalo, c = i - r * kSsimHalo;
+            const int gy = y0 + r - kSsimHalf, gx = x0 + c - kSsimHalf;
+            const bool in = i < kSsimHalo * kSsimHalo && gy >= 0 && gy < H && gx >= 0 && gx < W;     // no window is centred outside the image
+            const long long o = plane + (long long)gy * W + gx;
+            v0[u] = in ? maps[o] : 0.0f;
+            v1[u] = in ? maps[o + map_stride] : 0.0f;
+            v2[u] = in ? maps[o + 2 * map_stride] : 0.0f;
         }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
+#pragma unroll
+        for (int u = 0; u < kIters; u++) {
+            const int i = tid + u * kBlock;
+            if (i < kSsimHalo * kSsimHalo) { const int r = i / kSsimHalo, c = i - r * kSsimHalo; s_m[0][r][c] = v0[u]; s_m[1][r][c] = v1[u]; s_m[2][r][c] = v2[u]; }
+        }
     }
     __syncthreads();
-    const int r = tid / kSsimTile, c = tid - r * kSsimTile;
-    const int gy = y0 + r, gx = x0 + c;
-    if (gy >= H || gx >= W) return;
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kSsimTaps; k++) {
-        const float w = win.g[k];
-        c0 += w * s_h[0][r + k][c]; c1 += w * s_h[1][r + k][c]; c2 += w * s_h[2][r + k][c];
-    }
-    const long long o = plane + (long long)gy * W + gx;
-    const float xv = pred[o], yv = target[o];
+    const SsimTaps T = ssim_taps(win);
+    ssim_rows<3>(T, s_h, [&](float* v, int r, int c) { v[0] = s_m[0][r][c]; v[1] = s_m[1][r][c]; v[2] = s_m[2][r][c]; });
+    __syncthreads();
+    const int c = tid & (kSsimTile - 1), r0 = (tid / kSsimTile) * kSsimRun;
+    float cv[3][kSsimRun];
+    ssim_cols<3>(T, s_h, r0, c, cv);
+    const int gx = x0 + c;
     const float g = (upstream ? upstream[0] : 1.0f) / (float)n;
-    const float d = xv - yv;
-    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    d_pred[o] = g * ((1.0f - lambda) * sgn - lambda * (c0 + 2.0f * xv * c1 + yv * c2));
+#pragma unroll
+    for (int o = 0; o < kSsimRun; o++) {
+        const int gy = y0 + r0 + o;
+        if (gy < H && gx < W) {
+            const long long oo = plane + (long long)gy * W + gx;
+            const float xv = pred[oo], yv = target[oo];
+            const float d = xv - yv;
+            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            d_pred[oo] = g * ((1.0f - lambda) * sgn - lambda * (cv[0][o] + 2.0f * xv * cv[1][o] + yv * cv[2][o]));
+        }
+    }
 }
 
 static SsimWindow ssim_window()
@@ -324,7 +419,7 @@ GSX_API int gsx_l1_ssim_fwd(const float* pred, const float* target, int32_t plan
     const long long n = (long long)planes * H * W;
     const dim3 grid((unsigned)ceil_div(W, kSsimTile), (unsigned)ceil_div(H, kSsimTile), (unsigned)planes);
     ssim_fwd_kernel<<<grid, dim3(kBlock), 0, st>>>(pred, target, H, W, ssim_window(), maps, n, partials);
-    ssim_final_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(partials, ssim_blocks(planes, H, W), n, lambda_dssim, loss3);
+    ssim_final_kernel<<<dim3(1), dim3(kSsimFinalThreads), 0, st>>>(partials, ssim_blocks(planes, H, W), n, lambda_dssim, loss3);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
