@@ -88,13 +88,13 @@ def lib():
 
 
 def stream_ptr():
-    """torch's current HIP stream on the current device as a c_void_p (the raw-handle getters are ~20x cheaper than
+    """torch's current HIP stream on the current device as an integer handle (the raw-handle getters are ~20x cheaper than
     torch.cuda.current_stream(), which a trainer step would otherwise call a dozen times)."""
     import torch
     try:
-        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())      # an int: converted per argtypes
     except AttributeError:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return torch.cuda.current_stream().cuda_stream
 
 
 def check(status, where):

@@ -10,7 +10,7 @@ L1, CLAMPED_MSE = 0, 1
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
 _stream = L.stream_ptr
