@@ -21,6 +21,7 @@ SYMBOLS = [
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
+ABI_VERSION = 9             # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -50,6 +51,9 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {os.path.dirname(LIB_PATH)}`; there is no CPU/torch fallback for the render path")
     L = C.CDLL(LIB_PATH)
+    L.gsx_abi_version.restype = C.c_int
+    if L.gsx_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI {L.gsx_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild it (make -C {os.path.dirname(LIB_PATH)})")
     L.gsx_strerror.restype = C.c_char_p; L.gsx_strerror.argtypes = [C.c_int]
     L.gsx_last_hip_error.restype = C.c_int
     L.gsx_abi_version.restype = C.c_int

@@ -736,4 +736,4 @@ GSX_API const char* gsx_strerror(int status)
     }
 }
 GSX_API int gsx_last_hip_error(void) { return gsx::g_last_hip_error; }
-GSX_API int gsx_abi_version(void) { return 9; }
+GSX_API int gsx_abi_version(void) { return GSX_ABI_VERSION; }

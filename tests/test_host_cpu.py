@@ -13,6 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PARAMS = ["positions", "scales", "rotations", "opacity", "features"]
 
 
+def test_graft_entry_build_runs():
+    """build() is what the driver runs first: it must compile (a no-op when up to date), load the library and agree on the ABI"""
+    import __graft_entry__ as g
+    g.build()
+
+
 def test_cabi_exports_every_declared_symbol():
     from gaussian_splatting_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
@@ -22,7 +28,8 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsx.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.gsx_abi_version() == 9
+    assert lib.gsx_abi_version() == _lib.ABI_VERSION
+    assert f"#define GSX_ABI_VERSION {_lib.ABI_VERSION}\n" in hdr
     assert lib.gsx_strerror(-2).decode().startswith("instance buffers")
     # pure host helpers (no GPU): workspace sizes and the chunk bound
     assert lib.gsx_sort_workspace_bytes(1 << 20) >= 256 * 256 * 4
