@@ -346,14 +346,19 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                 }
                 const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
                 uint32_t* cnt = work_counters(work, PASS1);
+                // lane k reserves class k's slots: the five atomics are in flight together (one L2 round trip per batch;
+                // issued one after the other they were most of a long tile's time in this kernel)
+                uint32_t mine = 0, below = 0;
 #pragma unroll
                 for (int k = 0; k < kWorkClasses; k++) {
                     const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == k);
-                    uint32_t base = 0;
-                    if (threadIdx.x == 0 && mk) base = atomicAdd(cnt + k, (uint32_t)__popcll(mk));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (cls == k) work_list(work, PASS1, k, max_chunks)[base + (uint32_t)__popcll(mk & lt)] = c;
+                    if ((int)threadIdx.x == k) mine = (uint32_t)__popcll(mk);
+                    if (cls == k) below = (uint32_t)__popcll(mk & lt);
                 }
+                uint32_t base = 0;
+                if (threadIdx.x < kWorkClasses && mine) base = atomicAdd(cnt + threadIdx.x, mine);
+                base = (uint32_t)__shfl((int)base, cls < 0 ? 0 : cls, 64);
+                if (cls >= 0) work_list(work, PASS1, cls, max_chunks)[base + below] = c;
             }
             __syncthreads();
         }

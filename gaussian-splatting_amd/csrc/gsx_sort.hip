@@ -72,7 +72,13 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t acc = 0;
     const int64_t before = (int64_t)blockIdx.x * ratio;
-    for (int64_t j = threadIdx.x; j < before; j += kBlock) acc += sums[j];
+    {
+        int64_t j = threadIdx.x;                      // 4 loads in flight: the last workgroups walk ~16 strides of the table
+        uint64_t a1 = 0, a2 = 0, a3 = 0;
+        for (; j + 3 * kBlock < before; j += 4 * kBlock) { acc += sums[j]; a1 += sums[j + kBlock]; a2 += sums[j + 2 * kBlock]; a3 += sums[j + 3 * kBlock]; }
+        for (; j < before; j += kBlock) acc += sums[j];
+        acc += (a1 + a2) + a3;
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
     if (lane == 0) s_pre[wave] = acc;
