@@ -307,6 +307,19 @@ def test_async_binning_matches_synchronous(dev, cap):
     R._scratch.capacity.pop(dev, None)
 
 
+def test_tile_sort_beyond_one_workgroup_per_cu(dev, O):
+    """More than 256 x 16384 instances on <= 4096 tiles: the one-pass tile sort then runs several workgroups per CU at its
+    largest keys-per-workgroup setting (config 4's regime).  Integer products against the oracle, image at tolerance."""
+    params = synth_scene(300000, 41, 0.01, 0.04)
+    H = W = 1024
+    pose = pose_tz(2.0)
+    gp = gpu_pipeline(params, pose, H, W, dev)
+    assert gp["D"] > 256 * 16384, gp["D"]
+    fw = O.forward(params, pose, H, W, "tiled")
+    assert_integer_products_equal(gp, fw)
+    assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
+
+
 def test_optimistic_depth_sort_recovers(dev, O):
     """The render path sorts the depth keys on 24 bits while their top byte is constant (three radix passes instead of
     four) and learns from the sort's own mismatch count, which travels with the instance count, whether that held.
