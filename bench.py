@@ -116,7 +116,7 @@ def main():
     def step(s):
         v = (s * world + rank) % n_views
         if args.inference:
-            model.render_frames(poses[v:v + 1], (H, W))
+            raise RuntimeError("inference steps go through orbit_pass()")
         elif args.no_optimizer:
             opt.zero_grad()
             out = net(poses[v:v + 1], (H, W))
@@ -130,12 +130,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        step(s)
+    def orbit_pass(first, count):
+        """forward-only: `count` views of this rank's share of the orbit in ONE render_frames call (views pipelined over streams)"""
+        idx = torch.tensor([((first + i) * world + rank) % n_views for i in range(count)], device=dev)
+        model.render_frames(poses[idx], (H, W))
+
+    def run(first, count):
+        if args.inference:
+            done = 0
+            while done < count:
+                k = min(n_views, count - done)
+                orbit_pass(first + done, k); done += k
+        else:
+            for s in range(count):
+                step(first + s)
+
+    run(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s)
+    run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -80,10 +80,12 @@ class _Scratch:
         torch.cuda.empty_cache()
 
     def count_slot(self, dev):
-        """(pinned int64[2], event) for the asynchronous read-back of the instance count and the depth sort's mismatch count"""
-        if dev not in self.pinned:
-            self.pinned[dev] = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
-        return self.pinned[dev]
+        """(pinned int64[2], event) for the asynchronous read-back of the instance count and the depth sort's mismatch
+        count; one per stream, so that views in flight on different streams (render_orbit) do not share it"""
+        key = (dev, L.stream_ptr())
+        if key not in self.pinned:
+            self.pinned[key] = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        return self.pinned[key]
 
 
 _scratch = _Scratch()
@@ -251,42 +253,67 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
     # bits is redone on all 32.
     global _last_D
     dev = pre.device
-    given_order = order
-    while True:
-        total = torch.empty(2, dtype=torch.int64, device=dev)
-        bits = 32
-        if given_order is None:
-            bits = _scratch.depth_bits.get(dev, 32)
-            order = depth_order(keys, bits, total[1:])
-        rec, tt, rank_of = build_records(pre, order, H, W)
-        offsets, total, (pinned, ev) = bin_count(tt, total)
-        cap = _scratch.cap(dev, n)
-        tiles, ranks, ranges, chunk_base = bin_emit_sort(rec, offsets, total, n, H, W, cap)
-        rgb, alpha, dmap, state, chunk_state, max_chunks = composite_forward(rec, ranks, ranges, chunk_base, n, H, W, cap,
-                                                                              want_depth, need_bwd)
-        ev.synchronize()
-        D = int(pinned[0])
-        redo = False
-        if given_order is None:
-            constant_top = int(pinned[1]) == 0
-            _scratch.depth_bits[dev] = DEPTH_CHECK_BIT if constant_top else 32
-            redo = bits < 32 and not constant_top
-        if D >= 0xFFFFFFFF:
-            raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
-        if D > cap:
-            redo = True
-        if not redo:
-            break
-        del tiles, ranks, ranges, chunk_base, rgb, alpha, dmap, state, chunk_state     # results of the failed attempt
-        if D > cap:
-            _scratch.grow(dev, D)
-    _last_D = D
+    att = _enqueue_view(pre, keys, n, H, W, order, want_depth, need_bwd)
+    while not _check_view(att):
+        att = _enqueue_view(pre, keys, n, H, W, order, want_depth, need_bwd)
+    return _finish_view(att, pose, mean2d, depth, cov2d)
+
+
+class _Attempt:
+    """One enqueued view (everything after the projection) whose instance count the host has not looked at yet."""
+    __slots__ = ("order", "rec", "tt", "rank_of", "offsets", "tiles", "ranks", "ranges", "chunk_base", "rgb", "alpha", "dmap", "state",
+                 "chunk_state", "max_chunks", "cap", "bits", "sorted_here", "pinned", "ev", "dev", "n", "H", "W", "D")
+
+
+def _enqueue_view(pre, keys, n, H, W, given_order, want_depth, need_bwd):
+    a = _Attempt()
+    dev = a.dev = pre.device
+    a.n, a.H, a.W = n, H, W
+    total = torch.empty(2, dtype=torch.int64, device=dev)
+    a.bits, a.sorted_here = 32, given_order is None
+    if given_order is None:
+        a.bits = _scratch.depth_bits.get(dev, 32)
+        a.order = depth_order(keys, a.bits, total[1:])
+    else:
+        a.order = given_order
+    a.rec, a.tt, a.rank_of = build_records(pre, a.order, H, W)
+    a.offsets, total, (a.pinned, a.ev) = bin_count(a.tt, total)
+    a.cap = _scratch.cap(dev, n)
+    a.tiles, a.ranks, a.ranges, a.chunk_base = bin_emit_sort(a.rec, a.offsets, total, n, H, W, a.cap)
+    a.rgb, a.alpha, a.dmap, a.state, a.chunk_state, a.max_chunks = composite_forward(a.rec, a.ranks, a.ranges, a.chunk_base, n, H, W, a.cap,
+                                                                                     want_depth, need_bwd)
+    return a
+
+
+def _check_view(a):
+    """Waits for the attempt's instance count (the GPU is still compositing) -> True if its results stand; otherwise the
+    scratch capacity / depth-sort width have been corrected and the view must be enqueued again."""
+    a.ev.synchronize()
+    a.D = D = int(a.pinned[0])
+    redo = False
+    if a.sorted_here:
+        constant_top = int(a.pinned[1]) == 0
+        _scratch.depth_bits[a.dev] = DEPTH_CHECK_BIT if constant_top else 32
+        redo = a.bits < 32 and not constant_top
+    if D >= 0xFFFFFFFF:
+        raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
+    if D > a.cap:
+        redo = True
+        for k in ("tiles", "ranks", "ranges", "chunk_base", "rgb", "alpha", "dmap", "state", "chunk_state"):
+            setattr(a, k, None)                   # truncated results: release them before the buffers grow
+        _scratch.grow(a.dev, D)
+    return not redo
+
+
+def _finish_view(a, pose, mean2d, depth, cov2d):
+    global _last_D
+    _last_D = a.D
     vs = ViewState()
-    vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, order, rank_of, rec, tt, offsets
-    vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = ranks, ranges, chunk_base, chunk_state, max_chunks
-    vs.state, vs.D, vs.H, vs.W, vs.cap = state, D, H, W, cap
-    vs_extra = dict(tiles=tiles)
-    return (rgb, alpha, dmap, mean2d, depth, cov2d), vs, vs_extra
+    vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, a.order, a.rank_of, a.rec, a.tt, a.offsets
+    vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = a.ranks, a.ranges, a.chunk_base, a.chunk_state, a.max_chunks
+    vs.state, vs.D, vs.H, vs.W, vs.cap = a.state, a.D, a.H, a.W, a.cap
+    vs_extra = dict(tiles=a.tiles)
+    return (a.rgb, a.alpha, a.dmap, mean2d, depth, cov2d), vs, vs_extra
 
 
 def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumulate):
@@ -374,11 +401,14 @@ def render_views(positions, scales, rotations, opacity, features, poses, image_s
 
 
 @torch.no_grad()
-def render_orbit(positions, scales, rotations, opacity, features, poses, image_size, out=None):
+def render_orbit(positions, scales, rotations, opacity, features, poses, image_size, out=None, streams=2):
     """the inference caller of the path (/root/reference/utils/visualization.py:343-347 renders an
-    orbit one `model(pose.unsqueeze(0), size)` call at a time).  Renders V poses (V,4,4) back to back into ONE
-    (V,3,H,W) tensor: no autograd node, no backward state (the combine pass skips its second scan and the chunk-end
-    transmittances), each view composited in its own depth order exactly as V separate forward calls would."""
+    orbit one `model(pose.unsqueeze(0), size)` call at a time).  Renders V poses (V,4,4) into ONE (V,3,H,W) tensor: no
+    autograd node, no backward state (the combine pass skips its second scan and the chunk-end transmittances), each
+    view composited in its own depth order exactly as V separate forward calls would.  The views are independent, so
+    they are enqueued round-robin on `streams` HIP streams: one view's launch-bound stretch (sorts, scans, binning: a
+    third of its time) overlaps another's compositing, and the host looks at a view's instance count only after it has
+    enqueued the next one."""
     if not positions.is_cuda:
         raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
                            "there is no CPU fallback")
@@ -386,8 +416,51 @@ def render_orbit(positions, scales, rotations, opacity, features, poses, image_s
     params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
     poses = _f32c(poses.detach().to(positions.device))
     V = poses.shape[0]
+    n = params[0].shape[0]
     frames = out if out is not None else torch.empty(V, 3, H, W, dtype=torch.float32, device=positions.device)
+    dev = positions.device
+    S = max(1, min(int(streams), V))
+    if S == 1:
+        for v in range(V):
+            o, _, _ = forward_view(params, poses[v], H, W, want_depth=False, need_bwd=False)
+            frames[v].copy_(o[0])
+        return frames
+    main = torch.cuda.current_stream(dev)
+    pool = _orbit_streams(dev, S)
+    start = torch.cuda.Event(); start.record(main)
+    in_flight = []
+
+    def retire(item):
+        v, s, att, pre, keys = item
+        with torch.cuda.stream(s):
+            while not _check_view(att):                       # rare: capacity or depth-sort width had to be corrected
+                att = _enqueue_view(pre, keys, n, H, W, None, False, False)
+            global _last_D
+            _last_D = att.D
+            frames[v].copy_(att.rgb)
+
     for v in range(V):
-        o, _, _ = forward_view(params, poses[v], H, W, want_depth=False, need_bwd=False)
-        frames[v].copy_(o[0])
+        s = pool[v % S]
+        with torch.cuda.stream(s):
+            if v < S:
+                s.wait_event(start)                           # parameters and poses were produced on the caller's stream
+            _, _, _, keys, pre = project(*params, poses[v])
+            att = _enqueue_view(pre, keys, n, H, W, None, False, False)
+        in_flight.append((v, s, att, pre, keys))
+        if len(in_flight) == S:
+            retire(in_flight.pop(0))
+    while in_flight:
+        retire(in_flight.pop(0))
+    for s in pool:
+        done = torch.cuda.Event(); done.record(s); main.wait_event(done)
     return frames
+
+
+_orbit_pool = {}
+
+
+def _orbit_streams(dev, count):
+    pool = _orbit_pool.setdefault(dev, [])
+    while len(pool) < count:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:count]
