@@ -16,20 +16,27 @@ size_t sort_ws_bytes_internal(int64_t n);
 // kEmitSolo tiles is written by its whole wavefront (lane l takes tiles l, l+64, ...): one screen-sized splat would
 // otherwise keep a single lane busy for thousands of iterations while the rest of the chip waits.
 constexpr int kEmitSolo = 32;
-__global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ offsets, int N, int tw,
+__global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ tile_box,
+                                                      const uint32_t* __restrict__ offsets, int N, int tw,
                                                       uint32_t capacity, uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0; uint32_t o = 0;
     if (r < N) {
-        const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
-        const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
-        const int xlo = bx & 0xffff, xhi = bx >> 16, ylo = by & 0xffff, yhi = by >> 16;
-        if (xlo <= xhi) {
-            x0 = xlo >> GSX_TILE_SHIFT; x1 = (xhi >> GSX_TILE_SHIFT) + 1;
-            y0 = ylo >> GSX_TILE_SHIFT; y1 = (yhi >> GSX_TILE_SHIFT) + 1;
-            o = offsets[r];
+        if (tile_box) {                               // packed footprint in tile units (gsx_build_records): 4 B per rank, coalesced
+            const uint32_t tb = tile_box[r];
+            const int a = tb & 0xff, b = (tb >> 8) & 0xff, c = (tb >> 16) & 0xff, d = tb >> 24;
+            if (a <= c) { x0 = a; x1 = c + 1; y0 = b; y1 = d + 1; o = offsets[r]; }
+        } else {
+            const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
+            const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
+            const int xlo = bx & 0xffff, xhi = bx >> 16, ylo = by & 0xffff, yhi = by >> 16;
+            if (xlo <= xhi) {
+                x0 = xlo >> GSX_TILE_SHIFT; x1 = (xhi >> GSX_TILE_SHIFT) + 1;
+                y0 = ylo >> GSX_TILE_SHIFT; y1 = (yhi >> GSX_TILE_SHIFT) + 1;
+                o = offsets[r];
+            }
         }
     }
     const int cnt = (x1 - x0) * (y1 - y0);
@@ -366,7 +373,7 @@ GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_bloc
     return GSX_OK;
 }
 
-GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                               int64_t capacity, const uint64_t* total_dev,
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                               uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream)
@@ -377,6 +384,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
     if (!ranges || !chunk_base || !total_dev || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
     if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
     if (N > 0 && (!rec || !offsets)) return GSX_E_INVALID;
+    if (W > 256 * GSX_TILE || H > 256 * GSX_TILE) tile_box = nullptr;       // the packed boxes hold 8-bit tile coordinates
     hipStream_t st = (hipStream_t)stream;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
@@ -392,7 +400,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
         uint32_t* hist = (uint32_t*)sub_ws;
         uint32_t* totals = (uint32_t*)((char*)sub_ws + align_up((size_t)nb * kTsDigits * 4));
         if (N > 0) {
-            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
+            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
             tile_hist_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
         }
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
@@ -406,7 +414,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t
     uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;
     uint32_t* e_r = (passes & 1) ? ranks_tmp : ranks_sorted;
     if (N > 0) {
-        emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, offsets, N, tw, (uint32_t)capacity, e_t, e_r);
+        emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, e_t, e_r);
         GSX_LAUNCH_CHECK();
         int s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, capacity, total_dev, 0, bits, sub_ws, sub_bytes, st);
         if (s != GSX_OK) return s;
@@ -445,6 +453,6 @@ GSX_API int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, i
     if (D >= 0xFFFFFFFFull) return GSX_E_RANGE;
     if ((int64_t)D > capacity) return GSX_E_CAPACITY;
     if (D == 0) return empty();
-    return gsx_bin_emit_sort(rec, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
+    return gsx_bin_emit_sort(rec, nullptr, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
                              ranges, chunk_base, chunk_force, ws, ws_bytes, stream);
 }

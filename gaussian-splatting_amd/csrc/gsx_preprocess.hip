@@ -132,7 +132,7 @@ __device__ __forceinline__ void block_sum_tiles(uint32_t tt, uint64_t* __restric
 __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
                                                                int N, int H, int W, float* __restrict__ rec,
                                                                uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of,
-                                                               uint64_t* __restrict__ tt_sums)
+                                                               uint64_t* __restrict__ tt_sums, uint32_t* __restrict__ tile_box)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= N) { if (tt_sums) block_sum_tiles(0u, tt_sums); return; }
@@ -167,6 +167,10 @@ __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __r
     uint32_t tt = 0;
     if (xlo <= xhi) tt = (uint32_t)(((xhi >> GSX_TILE_SHIFT) + 1 - (xlo >> GSX_TILE_SHIFT)) * ((yhi >> GSX_TILE_SHIFT) + 1 - (ylo >> GSX_TILE_SHIFT)));
     tiles_touched[r] = tt;
+    // the footprint in TILE units, one word per rank (images of up to 256 tiles a side): what the emit pass reads instead of
+    // pulling every 48-byte record through the cache for 8 bytes of it.  x0 | y0 << 8 | (x1 - 1) << 16 | (y1 - 1) << 24; empty: x0 > x1 - 1
+    if (tile_box) tile_box[r] = tt ? ((uint32_t)(xlo >> GSX_TILE_SHIFT) | ((uint32_t)(ylo >> GSX_TILE_SHIFT) << 8) |
+                                      ((uint32_t)(xhi >> GSX_TILE_SHIFT) << 16) | ((uint32_t)(yhi >> GSX_TILE_SHIFT) << 24)) : 0x00000001u;
     const uint32_t bx = (uint32_t)xlo | ((uint32_t)xhi << 16), by = (uint32_t)ylo | ((uint32_t)yhi << 16);
     float4* R = reinterpret_cast<float4*>(rec) + (size_t)3 * r;
     R[0] = make_float4(mu.x, mu.y, m[0] * GSX_NEG_HALF_LOG2E, (m[1] + m[2]) * GSX_NEG_HALF_LOG2E);
@@ -348,7 +352,8 @@ GSX_API int gsx_project_fwd(const float* positions, const float* scales, const f
 }
 
 GSX_API int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
-                              float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, void* stream)
+                              float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, uint32_t* tile_box,
+                              void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
@@ -357,7 +362,8 @@ GSX_API int gsx_build_records(const float* pre, const uint32_t* order, int32_t N
     // the per-wave partial sums are u32: 64 splats x n_tiles must fit
     if (tt_block_sums && (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE) > (int64_t)(0xFFFFFFFFu / 64u)) return GSX_E_RANGE;
     build_records_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of, tt_block_sums);
+        (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of, tt_block_sums,
+        (W <= 256 * GSX_TILE && H <= 256 * GSX_TILE) ? tile_box : nullptr);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

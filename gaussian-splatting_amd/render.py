@@ -134,10 +134,12 @@ def build_records(pre, order, H, W):
     tt = torch.empty(n, dtype=torch.int32, device=dev)
     rank_of = torch.empty(n, dtype=torch.int32, device=dev)
     tt_sums = torch.empty((n + 255) // 256, dtype=torch.int64, device=dev)
+    tile_box = torch.empty(n, dtype=torch.int32, device=dev) if max(H, W) <= 256 * L.TILE else None
     with _stage("build_records"):
-        L.check(lib.gsx_build_records(_ptr(pre), _ptr(order), n, H, W, _ptr(rec), _ptr(tt), _ptr(rank_of), _ptr(tt_sums), _stream()),
-                "gsx_build_records")
+        L.check(lib.gsx_build_records(_ptr(pre), _ptr(order), n, H, W, _ptr(rec), _ptr(tt), _ptr(rank_of), _ptr(tt_sums), _ptr(tile_box),
+                                      _stream()), "gsx_build_records")
     tt._gsx_block_sums = tt_sums               # travels with the tensor: bin_count(tt) then scans in one launch
+    rec._gsx_tile_box = tile_box               # likewise: bin_emit_sort(rec, ...) emits from the packed footprints
     return rec, tt, rank_of
 
 
@@ -202,7 +204,7 @@ def bin_emit_sort(rec, offsets, total, n, H, W, cap):
     wsb = lib.gsx_bin_workspace_bytes(n, cap)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     with _stage("bin_emit_sort"):
-        L.check(lib.gsx_bin_emit_sort(_ptr(rec), _ptr(offsets), n, H, W, cap, _ptr(total), _ptr(bufs[0]), _ptr(bufs[1]),
+        L.check(lib.gsx_bin_emit_sort(_ptr(rec), _ptr(getattr(rec, "_gsx_tile_box", None)), _ptr(offsets), n, H, W, cap, _ptr(total), _ptr(bufs[0]), _ptr(bufs[1]),
                                       _ptr(bufs[2]), _ptr(bufs[3]), _ptr(ranges), _ptr(chunk_base), _scratch.force_chunk, _ptr(ws), wsb, _stream()),
                 "gsx_bin_emit_sort")
     return bufs[0], bufs[1], ranges, chunk_base

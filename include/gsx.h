@@ -80,9 +80,12 @@ int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* total_de
  * pre: from gsx_project_fwd.  rec: N x GSX_REC_FLOATS floats (layout: gsx_constants.h);
  * tiles_touched: N (rank order); rank_of: N, inverse of order (rank_of[order[r]] = r).
  * tt_block_sums (nullable): ceil(N / 256) u64, sums of tiles_touched over consecutive groups of 256 ranks; handed to
- * gsx_bin_count they save its reduction launch. */
+ * gsx_bin_count they save its reduction launch.
+ * tile_box (nullable): N u32, the footprint in tile units (x0 | y0 << 8 | x1 << 16 | y1 << 24, inclusive; x0 > x1 = none),
+ * written for images of up to 256 tiles a side; handed to gsx_bin_emit_sort it replaces the strided read of the records. */
 int gsx_build_records(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
-                      float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, void* stream);
+                      float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, uint32_t* tile_box,
+                      void* stream);
 
 /* ---- binning: scan tiles_touched -> offsets, emit (tile, rank) instances, sort them by tile
  * (stable, so each tile's list stays in rank order == key (tile<<32 | rank) order), cut tile
@@ -117,7 +120,8 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
  *   capacity (gsx_max_chunks(capacity, H, W)), not from D. */
 int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, int32_t N, uint32_t* offsets, uint64_t* total_dev,
                   int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream);
-int gsx_bin_emit_sort(const float* rec, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box /* from gsx_build_records, or NULL */,
+                      const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                       int64_t capacity, const uint64_t* total_dev,
                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                       uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream);

@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu():
     assert lib.gsx_project_fwd(*nul, 5, *nul) == _lib.GSX_E_INVALID
     assert lib.gsx_project_fwd(*nul, -1, *nul) == _lib.GSX_E_INVALID
     assert lib.gsx_project_fwd(*nul, 0, *nul) == _lib.GSX_OK
-    assert lib.gsx_build_records(None, None, 4, 70000, 8, None, None, None, None, None) == _lib.GSX_E_INVALID
+    assert lib.gsx_build_records(None, None, 4, 70000, 8, None, None, None, None, None, None) == _lib.GSX_E_INVALID
     assert lib.gsx_sort_pairs_u32(None, None, None, None, None, None, 10, 0, 33, 32, None, None, 0, None) == _lib.GSX_E_INVALID
 
 
