@@ -269,6 +269,14 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
         }
         __builtin_amdgcn_sched_barrier(0);                              // one round at a time: interleaved rounds spill (128 VGPRs at 1024 threads)
     }
+    // the values are read only now (16 registers fewer across the ranking), and early enough that their latency hides
+    // behind the prefix and scan steps below
+    uint32_t val[kTsItems];
+#pragma unroll
+    for (int k = 0; k < kTsItems; k++) {
+        const uint32_t li = wlane + k * 64;
+        val[k] = (k < items && li < here) ? vin[li] : 0u;
+    }
     __syncthreads();
     // per tile: exclusive prefix of the 16 waves' counts (fits 16 bits: <= 16384 keys per workgroup).  Thread t owns tiles
     // 4t .. 4t+3 = one uint2 of packed u16 pairs per wave row.
@@ -300,8 +308,8 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
     uint16_t* s_key = reinterpret_cast<uint16_t*>(s_val + kTsThreads * kTsItems);      // 16384 x 2 B
 #pragma unroll
     for (int k = 0; k < kTsItems; k++) {
-        const uint32_t li = wlane + k * 64;                             // the values are read only now: 16 registers fewer across the ranking
-        if (k < items && li < here) { const uint32_t pos = key[k] >> kTsBits; s_val[pos] = vin[li]; s_key[pos] = (uint16_t)(key[k] & (kTsDigits - 1)); }
+        const uint32_t li = wlane + k * 64;
+        if (k < items && li < here) { const uint32_t pos = key[k] >> kTsBits; s_val[pos] = val[k]; s_key[pos] = (uint16_t)(key[k] & (kTsDigits - 1)); }
     }
     __syncthreads();
 #pragma unroll
