@@ -117,7 +117,7 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
  *   `capacity` (which sizes the launches): no host synchronisation.  If D turns out to exceed capacity the
  *   results are truncated (never out of bounds); the caller detects that from the count and calls again with
  *   larger buffers.  ws: gsx_bin_workspace_bytes(N, capacity).  Size chunk_state / partials / launch grids from
- *   capacity (gsx_max_chunks(capacity, H, W)), not from D. */
+ *   capacity (gsx_max_chunks(capacity, H, W, chunk_force)), not from D. */
 int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_block_sums, int32_t N, uint32_t* offsets, uint64_t* total_dev,
                   int64_t* D_pinned_host, void* ws, size_t ws_bytes, void* stream);
 int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box /* from gsx_build_records, or NULL */,
@@ -132,7 +132,7 @@ int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box /* from gsx_bui
 int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W, int32_t chunk_force);
 
 /* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  A tile's depth-ordered
- * list is cut into chunks of GSX_CHUNK instances; one wave64 composites one chunk for the whole
+ * list is cut into chunks of 64 / 128 / GSX_CHUNK instances (chunk_base[n_tiles + 1]); one wave64 composites one chunk for the whole
  * 16x16 tile (4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
  * the chunks (compositing is associative), writes the image and -- with need_bwd -- each chunk's dark-quadrant
  * bytes and the backward's work lists.  Enqueues, in order: chunk pass,
