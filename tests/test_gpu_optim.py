@@ -120,9 +120,9 @@ def test_fused_l1_ssim_matches_torch(shape, lam):
     ld = (1 - lam) * (xd - td.double()).abs().mean() + lam * (1 - _torch_ssim_f64(xd, td.double()))
     lb, terms = gl.l1_ssim(xb, td, lam, return_terms=True)
     (la * 2.0).backward(); (lb * 2.0).backward(); (ld * 2.0).backward()
-    assert abs(float(lb) - float(ld)) <= 2e-6, (float(lb), float(ld), float(la))
+    assert abs(float(lb.detach()) - float(ld.detach())) <= 2e-6, (float(lb.detach()), float(ld.detach()), float(la.detach()))
     assert abs(float(terms[1]) - float((xd - td.double()).abs().mean())) <= 1e-6
-    assert abs(float(terms[2]) - (1 - (float(ld) - (1 - lam) * float(terms[1])) / lam)) <= 1e-5
+    assert abs(float(terms[2]) - (1 - (float(ld.detach()) - (1 - lam) * float(terms[1])) / lam)) <= 1e-5
     ref = xd.grad.float()
     scale = ref.abs().max().item()
     err = (xb.grad - ref).abs().max().item(); err_torch = (xa.grad - ref).abs().max().item()

@@ -455,15 +455,25 @@ def test_full_size_properties(dev):
         assert np.array_equal(getattr(m, k).grad.cpu().numpy(), g1[k]), k
 
 
-def test_full_size_vs_oracle(dev, O):
-    """The bench workload itself -- config 3, orbit view 10: 1 M Gaussians on 1024^2, 2.6 M instances, 256-instance chunks,
-    half of them occluded -- directly against the CPU restatement (a few seconds of 16 threads): integer products
+FULL_SIZE = {
+    # config 3 = the bench workload: 1 M Gaussians on 1024^2, orbit view 10 (2.6 M instances, 256-instance chunks, half occluded)
+    "c3_orbit_view10": lambda: (synth_scene(1_000_000, 5, 0.001, 0.005), orbit_pose(10), 1024, 1024),
+    # config 2 at its own size and camera: 100 k Gaussians on 800^2, M = I with tz = 2
+    "c2_100k_800x800": lambda: (synth_scene(100_000, 2, 0.002, 0.01), pose_tz(2.0), 800, 800),
+    # config 4's per-GPU share: 3 M Gaussians on 1024^2, orbit view 7 (one of its eight views)
+    "c4_3M_orbit_view7": lambda: (synth_scene(3_000_000, 6, 0.001, 0.005), orbit_pose(7), 1024, 1024),
+    # config 5's image (1920x1080: 8160 tiles, the generic two-pass tile sort), splat sizes and quantised depths at 1/1000 of
+    # its Gaussian count (the oracle's time goes with the instance count: millions here, billions at 6 M)
+    "c5_6k_1920x1080": lambda: (synth_scene(6_000, 8, 0.01, 0.1, zq=64.0), pose_tz(2.0), 1080, 1920),
+}
+
+
+@pytest.mark.parametrize("case", list(FULL_SIZE))
+def test_full_size_vs_oracle(dev, O, case):
+    """BASELINE configs at FULL size directly against the CPU restatement (a few seconds of 16 threads): integer products
     bit-exact, RGB 1e-4 max-abs, gradients 1e-3 relative."""
-    params = synth_scene(1_000_000, 5, 0.001, 0.005)
-    H = W = 1024
-    pose = orbit_pose(10)
+    params, pose, H, W = FULL_SIZE[case]()
     gp = gpu_pipeline(params, pose, H, W, dev)
-    assert gp["D"] > (1 << 20)                                       # full-length chunks
     fw = O.forward(params, pose, H, W, "tiled")
     assert_integer_products_equal(gp, fw)
     assert gp["n_composited"] == fw["n_composited"]
