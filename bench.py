@@ -186,7 +186,8 @@ def main():
                     "avg_launch_ms": stages[dom], "avg_instances_D": int(d_avg),
                     "note": "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                             "(profiles/r1_pmc_hbm_traffic.json; reads x2 as the gfx950 guide prescribes). The kernel is "
-                            "VALU-issue bound (85% of issue slots, DESIGN.md 4): its HBM fraction is small by construction"}
+                            "VALU-issue bound (85% of the chip's VALU issue slots, SQ counters in profiles/r1_pmc_sq_counters.json, "
+                            "DESIGN.md 4): its HBM fraction is small by construction"}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
