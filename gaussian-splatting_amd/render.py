@@ -76,8 +76,11 @@ class _Scratch:
     def grow(self, dev, d):
         self.capacity[dev] = int(d) + max(int(d) >> 3, 4096)
         # every per-view buffer changes size with the capacity: hand the cached blocks of the old size back first, or
-        # at config-5 scale (tens of GB per buffer) the allocator's reserved-but-unusable blocks exhaust the device
-        torch.cuda.empty_cache()
+        # at config-5 scale (tens of GB per buffer) the allocator's reserved-but-unusable blocks exhaust the device.
+        # (~100 B of buffers per instance of capacity; below a couple of GB the stale blocks do no harm and emptying the
+        # cache would only make a small scene's first orbit stall on hipFree / hipMalloc)
+        if self.capacity[dev] * 100 > (2 << 30):
+            torch.cuda.empty_cache()
 
     def count_slot(self, dev):
         """(pinned int64[2], event) for the asynchronous read-back of the instance count and the depth sort's mismatch
