@@ -16,7 +16,7 @@ SYMBOLS = [
     "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
-    "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd",
+    "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd", "gsx_image_loss_fwd_grad",
     "gsx_l1_ssim_workspace_bytes", "gsx_l1_ssim_fwd", "gsx_l1_ssim_bwd",
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
@@ -80,6 +80,7 @@ def lib():
     L.gsx_image_loss_workspace_bytes.restype = _sz
     L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
     L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]
+    L.gsx_image_loss_fwd_grad.argtypes = [_i32, _p, _p, _i64, _p, _p, _p, _sz, _p]
     L.gsx_l1_ssim_workspace_bytes.restype = _sz; L.gsx_l1_ssim_workspace_bytes.argtypes = [_i32, _i32, _i32]
     L.gsx_l1_ssim_fwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p]
     L.gsx_l1_ssim_bwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p, _p]

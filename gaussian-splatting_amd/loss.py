@@ -16,6 +16,20 @@ def _ptr(t):
 _stream = L.stream_ptr
 
 
+_UNIT = {}
+
+
+def unit_gradient(loss):
+    """A cached scalar 1.0 on the loss's device: `loss.backward(gradient=unit_gradient(loss))` spares autograd's fill
+    launch, and the fused losses recognise it (by address) as "upstream = 1" and hand back the gradient they already
+    wrote in their forward pass instead of launching a backward kernel."""
+    key = (loss.device, loss.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        one = _UNIT[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return one
+
+
 class _ImageLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, kind):
@@ -27,14 +41,26 @@ class _ImageLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         wsb = lib.gsx_image_loss_workspace_bytes()
         ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
-        L.check(lib.gsx_image_loss_fwd(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(ws), wsb, _stream()), "gsx_image_loss_fwd")
         ctx.kind = kind
-        ctx.save_for_backward(p, t)
+        if ctx.needs_input_grad[0]:
+            # the loss is almost always the root of the backward: write dLoss/dpred for upstream 1 in the same pass
+            d = torch.empty_like(p)
+            L.check(lib.gsx_image_loss_fwd_grad(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(d), _ptr(ws), wsb, _stream()),
+                    "gsx_image_loss_fwd_grad")
+            ctx.save_for_backward(p, t, d)
+        else:
+            L.check(lib.gsx_image_loss_fwd(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(ws), wsb, _stream()), "gsx_image_loss_fwd")
+            ctx.save_for_backward(p, t)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        p, t = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        p, t = saved[0], saved[1]
+        if len(saved) == 3:
+            unit = _UNIT.get((g.device, g.dtype))
+            if unit is not None and g.data_ptr() == unit.data_ptr():
+                return saved[2], None, None                  # upstream is the cached 1.0: the forward already wrote this
         lib = L.lib()
         d = torch.empty_like(p)
         g = g.detach().contiguous().float()

@@ -67,18 +67,13 @@ def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
         + w_opacity * (o * (1 - o)).mean()
 
 
-_ONES = {}
-
-
 def _unit_gradient(loss):
-    """A cached 1.0 of the loss's device/dtype: `loss.backward()` would launch a fill kernel for it every step."""
-    if loss.dim() != 0:
+    """The cached 1.0 of loss.py (see there): no fill launch for the backward seed, and the fused losses skip their
+    backward kernel when they see it."""
+    if loss.dim() != 0 or not loss.is_cuda:
         return None
-    key = (loss.device, loss.dtype)
-    one = _ONES.get(key)
-    if one is None:
-        one = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
-    return one
+    from .loss import unit_gradient
+    return unit_gradient(loss)
 
 
 def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad_norm=0.1):

@@ -206,6 +206,11 @@ int gsx_image_loss_fwd(int32_t kind, const float* pred, const float* target, int
                        float* loss, void* ws, size_t ws_bytes, void* stream);
 int gsx_image_loss_bwd(int32_t kind, const float* pred, const float* target, int64_t n,
                        const float* upstream, float* d_pred, void* stream);
+/* forward and gradient in one pass for a loss that is the root of the backward: *loss as gsx_image_loss_fwd (same bits),
+ * d_pred_unit = dLoss/dpred for upstream 1 (what gsx_image_loss_bwd writes for upstream[0] == 1).  The trainer step
+ * (training/trainer.py:144-166: loss.backward() on the criterion's value) then needs no backward launch for the loss. */
+int gsx_image_loss_fwd_grad(int32_t kind, const float* pred, const float* target, int64_t n,
+                            float* loss, float* d_pred_unit, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- L1 + D-SSIM: (1 - lambda) * mean |pred - target| + lambda * (1 - mean SSIM(pred, target)), the criterion
  * BASELINE config 2 names ("render + L1/SSIM backward").  No counterpart in the reference (its SSIM is
