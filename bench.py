@@ -75,6 +75,8 @@ def main():
                     help="informational: forward-only orbit rendering (SURVEY 8f N1, render_frames); not the headline metric")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the multi-GPU path on one GPU: init RCCL with world 1 and run the collectives anyway")
+    ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh"),
+                    help="gradient exchange: one RCCL all-reduce (default) or all-to-all + local sum + all-gather (SURVEY 8e's mesh schedule)")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev)
     use_dp = world > 1 or args.force_dp
-    net = DataParallelSplat(model, force_collectives=args.force_dp) if use_dp else model
+    net = DataParallelSplat(model, force_collectives=args.force_dp, schedule=args.dp_schedule) if use_dp else model
     opt = make_optimizer(net, fused_clip_norm=None if args.torch_optimizer else 0.1)
     n_views = 60
     poses = torch.from_numpy(create_orbit_poses(4.0, n_views, 45.0)).to(dev)      # README.md:129-137

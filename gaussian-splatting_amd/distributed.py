@@ -7,6 +7,7 @@ tests).  The path shards over camera views; parameters are replicated; the only 
 the gradient average after the local backward.  There is nothing to overlap it with: every
 Gaussian's gradient is final only when the last tile of the last local view has finished.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -43,9 +44,17 @@ class DataParallelSplat(torch.nn.Module):
     gradients of a backward are final -- like DDP, the caller only calls loss.backward().
     """
 
-    def __init__(self, module, process_group=None, auto_sync=True, broadcast=True, force_collectives=False):
+    def __init__(self, module, process_group=None, auto_sync=True, broadcast=True, force_collectives=False, schedule=None):
         super().__init__()
         self.module = module
+        # "allreduce": one RCCL all-reduce (default).  "mesh": the direct schedule of SURVEY 8e -- every rank sends slice j of
+        # its gradients straight to rank j (all-to-all: all seven xGMI links of a GPU carry S/8 at once), sums the eight
+        # slices it received in rank order, and the averaged slices are all-gathered.  2*(S/8) per link instead of a
+        # ring's 2*(7/8)*S through every link; whether that beats RCCL's own choice needs the 8-GPU node to tell
+        # (GSX_DP_SCHEDULE=mesh or bench.py --dp-schedule mesh), so it is opt-in.
+        self.schedule = schedule or os.environ.get("GSX_DP_SCHEDULE", "allreduce")
+        if self.schedule not in ("allreduce", "mesh"):
+            raise ValueError(f"unknown data-parallel schedule {self.schedule!r}")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())   # world 1: rehearsal only
@@ -87,7 +96,9 @@ class DataParallelSplat(torch.nn.Module):
         self.last_sync_was_flat = not packed
         if packed:
             flat = torch.cat([g.reshape(-1) for g in grads])
-        if flat.is_cuda and dist.get_backend(self.group) == "nccl":
+        if self.schedule == "mesh":
+            self._mesh_average(flat)
+        elif flat.is_cuda and dist.get_backend(self.group) == "nccl":
             # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
         else:                                   # gloo (CPU tests) has no AVG
@@ -98,6 +109,27 @@ class DataParallelSplat(torch.nn.Module):
             off = 0
             for g in grads:
                 g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+
+def _mesh_average_impl(flat, world, group):
+    """flat <- mean over ranks, by all-to-all + local sum + all-gather.  Every rank reduces its own slice in rank order, so
+    all ranks end up with the same bits (the replicas must not drift apart)."""
+    n = flat.numel()
+    chunk = (n + world - 1) // world
+    padded = chunk * world != n
+    send = flat
+    if padded:
+        send = flat.new_zeros(chunk * world); send[:n] = flat
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)            # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY slice
+    mine = recv.view(world, chunk).sum(0)
+    mine.mul_(1.0 / world)
+    dist.all_gather_into_tensor(send, mine, group=group)
+    if padded:
+        flat.copy_(send[:n])
+
+
+DataParallelSplat._mesh_average = lambda self, flat: _mesh_average_impl(flat, self.world, self.group)
 
 
 def reduce_metric(value, device=None, group=None):

@@ -140,7 +140,7 @@ rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 torch.manual_seed(100 + rank)                      # ranks start with DIFFERENT parameters
 m = GaussianSplat(50)
-dp = DataParallelSplat(m)                          # broadcast from rank 0 (trainer.py:83-87)
+dp = DataParallelSplat(m, schedule=sys.argv[2])    # broadcast from rank 0 (trainer.py:83-87)
 torch.manual_seed(100); m0 = GaussianSplat(50)
 for k in PARAM_ORDER:
     assert torch.equal(getattr(m, k).data, getattr(m0, k).data), k
@@ -172,15 +172,18 @@ print("rank", rank, "ok")
 '''
 
 
-def test_data_parallel_gradient_path_gloo_world2(tmp_path):
+@pytest.mark.parametrize("schedule,world", [("allreduce", 2), ("mesh", 2), ("mesh", 3)])
+def test_data_parallel_gradient_path_gloo(tmp_path, schedule, world):
+    """world 2 (and 3 for the mesh schedule: 14*50 gradients do not divide by 3, so its padded path runs)"""
     script = tmp_path / "dp_worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+    port = str(29611 + world + (10 if schedule == "mesh" else 0))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, schedule],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def _maint_module(n, seed):
