@@ -129,13 +129,11 @@ __device__ __forceinline__ void block_sum_tiles(uint32_t tt, uint64_t* __restric
     if (threadIdx.x == 0) tt_sums[blockIdx.x] = ((uint64_t)s_tt[0] + s_tt[1]) + ((uint64_t)s_tt[2] + s_tt[3]);
 }
 
-__global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
-                                                               int N, int H, int W, float* __restrict__ rec,
-                                                               uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of,
-                                                               uint64_t* __restrict__ tt_sums, uint32_t* __restrict__ tile_box)
+// one rank: gathers the Gaussian's packed row, writes its record, footprint and inverse-order entry; returns tiles_touched
+__device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ pre, const uint32_t* __restrict__ order, int r,
+                                                     int H, int W, float* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+                                                     uint32_t* __restrict__ rank_of, uint32_t* __restrict__ tile_box)
 {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= N) { if (tt_sums) block_sum_tiles(0u, tt_sums); return; }
     const uint32_t g = order[r];
     rank_of[g] = (uint32_t)r;
     const float4 p0 = pre[(size_t)3 * g], p1 = pre[(size_t)3 * g + 1], p2 = pre[(size_t)3 * g + 2];
@@ -176,7 +174,17 @@ __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __r
     R[0] = make_float4(mu.x, mu.y, m[0] * GSX_NEG_HALF_LOG2E, (m[1] + m[2]) * GSX_NEG_HALF_LOG2E);
     R[1] = make_float4(m[3] * GSX_NEG_HALF_LOG2E, op, p2.x, p2.y);
     R[2] = make_float4(p2.z, p1.z, __uint_as_float(bx), __uint_as_float(by));
-    if (tt_sums) block_sum_tiles(tt, tt_sums);
+    return tt;
+}
+
+__global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
+                                                               int N, int H, int W, float* __restrict__ rec,
+                                                               uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of,
+                                                               uint64_t* __restrict__ tt_sums, uint32_t* __restrict__ tile_box)
+{
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t tt = (r < N) ? build_record_one(pre, order, r, H, W, rec, tiles_touched, rank_of, tile_box) : 0u;
+    if (tt_sums) block_sum_tiles(tt, tt_sums);          // every thread of the workgroup reaches the barrier inside
 }
 
 // ------------------------------------------------------------------------------------------
