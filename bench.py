@@ -8,7 +8,7 @@ configuration: 1M Gaussians, 1024x1024, the 60-view orbit of config 3 (SURVEY 8d
 
 A "step" is one trainer step on one view per GPU (trainer.py:134-175 sequence): zero_grad ->
 render forward -> L1 loss -> render backward -> [N>1: one RCCL all-reduce of the flat 14*N
-gradient buffer] -> clip_grad_norm_(0.1) -> Adam step.  View of rank r at step s is
+gradient buffer, or the all-to-all + all-gather mesh schedule if that timed faster at start-up] -> clip_grad_norm_(0.1) -> Adam step.  View of rank r at step s is
 (s*N + r) mod 60: views are sharded over GPUs, per-GPU work is fixed (weak scaling).
 value = N * K * H * W / max-over-ranks wall time / 1e6 (Mpix/s), inputs resident in HBM.
 
@@ -75,8 +75,9 @@ def main():
                     help="informational: forward-only orbit rendering (SURVEY 8f N1, render_frames); not the headline metric")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the multi-GPU path on one GPU: init RCCL with world 1 and run the collectives anyway")
-    ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh"),
-                    help="gradient exchange: one RCCL all-reduce (default) or all-to-all + local sum + all-gather (SURVEY 8e's mesh schedule)")
+    ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh", "auto"),
+                    help="gradient exchange: one RCCL all-reduce (default), all-to-all + local sum + all-gather (SURVEY 8e's mesh "
+                         "schedule), or auto = time both on a scratch buffer at the first exchange and keep the faster")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
@@ -108,7 +109,12 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev)
     use_dp = world > 1 or args.force_dp
-    net = DataParallelSplat(model, force_collectives=args.force_dp, schedule=args.dp_schedule) if use_dp else model
+    # N>1 default "auto": both exchange schedules are timed once, here, on a scratch buffer of the gradients' size
+    # (outside warm-up and timed region alike) and the faster is kept; the line reports the choice and both timings
+    schedule = args.dp_schedule or os.environ.get("GSX_DP_SCHEDULE", "auto")
+    net = DataParallelSplat(model, force_collectives=args.force_dp, schedule=schedule) if use_dp else model
+    if use_dp and net.schedule == "auto":
+        net.tune_schedule(14 * n, dev)
     opt = make_optimizer(net, fused_clip_norm=None if args.torch_optimizer else 0.1)
     n_views = 60
     poses = torch.from_numpy(create_orbit_poses(4.0, n_views, 45.0)).to(dev)      # README.md:129-137
@@ -192,7 +198,7 @@ def main():
                             "DESIGN.md 4): its HBM fraction is small by construction"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # N=1 only: the other ranks would sit in the teardown meanwhile
         from oracle import gsx_oracle as O          # checker / reported baseline only
         O.lib()
         all_poses = create_orbit_poses(4.0, n_views, 45.0)
@@ -221,7 +227,8 @@ def main():
                                    f"one trainer step per view per GPU"
                                    + (" (INFERENCE: forward only, not the headline metric)" if args.inference else " (render fwd+bwd only)" if args.no_optimizer else (f" (fwd + {args.loss.upper()} + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
                                       else f" (fwd + {args.loss.upper()} + bwd + fused clip_grad_norm+Adam)")),
-                       "views_per_step": world, "parallelism": f"dp{world} over views"},
+                       "views_per_step": world, "parallelism": f"dp{world} over views",
+                       **({"gradient_exchange": net.schedule, "exchange_ms_on_scratch": net.tuned_ms} if use_dp else {})},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
         }
         print(json.dumps(line), flush=True)

@@ -51,10 +51,12 @@ class DataParallelSplat(torch.nn.Module):
         # its gradients straight to rank j (all-to-all: all seven xGMI links of a GPU carry S/8 at once), sums the eight
         # slices it received in rank order, and the averaged slices are all-gathered.  2*(S/8) per link instead of a
         # ring's 2*(7/8)*S through every link; whether that beats RCCL's own choice needs the 8-GPU node to tell
-        # (GSX_DP_SCHEDULE=mesh or bench.py --dp-schedule mesh), so it is opt-in.
+        # (GSX_DP_SCHEDULE=mesh or bench.py --dp-schedule mesh), so it is opt-in.  "auto": the first exchange times both
+        # on a scratch buffer of the gradients' size and every rank adopts the same winner (tune_schedule below).
         self.schedule = schedule or os.environ.get("GSX_DP_SCHEDULE", "allreduce")
-        if self.schedule not in ("allreduce", "mesh"):
+        if self.schedule not in ("allreduce", "mesh", "auto"):
             raise ValueError(f"unknown data-parallel schedule {self.schedule!r}")
+        self.tuned_ms = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())   # world 1: rehearsal only
@@ -96,19 +98,49 @@ class DataParallelSplat(torch.nn.Module):
         self.last_sync_was_flat = not packed
         if packed:
             flat = torch.cat([g.reshape(-1) for g in grads])
-        if self.schedule == "mesh":
-            self._mesh_average(flat)
-        elif flat.is_cuda and dist.get_backend(self.group) == "nccl":
-            # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:                                   # gloo (CPU tests) has no AVG
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / self.world)
+        if self.schedule == "auto":
+            self.tune_schedule(flat.numel(), flat.device)
+        self._average(flat, self.schedule)
         self.last_allreduce_bytes = flat.numel() * flat.element_size()
         if packed:
             off = 0
             for g in grads:
                 g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+
+def _average_impl(self, flat, schedule):
+    if schedule == "mesh":
+        _mesh_average_impl(flat, self.world, self.group)
+    elif flat.is_cuda and dist.get_backend(self.group) == "nccl":
+        # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+    else:                                   # gloo (CPU tests) has no AVG
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+
+
+def _tune_schedule_impl(self, numel, device, reps=3):
+    """Times both exchange schedules on a scratch buffer of `numel` floats (one untimed call each, then `reps` timed ones
+    between barriers) and adopts the faster.  The two timings are MAX-reduced over the ranks before they are compared, so
+    every rank takes the same decision -- ranks on different schedules would deadlock in the next exchange."""
+    import time
+    buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
+    times = []
+    for sched in ("allreduce", "mesh"):
+        self._average(buf, sched)
+        sync(); dist.barrier(group=self.group); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self._average(buf, sched)
+        sync()
+        times.append((time.perf_counter() - t0) / reps)
+    t = torch.tensor(times, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+    t = [float(x) for x in t.cpu()]
+    self.tuned_ms = {"allreduce": round(t[0] * 1e3, 4), "mesh": round(t[1] * 1e3, 4)}
+    self.schedule = "allreduce" if t[0] <= t[1] else "mesh"
+    return self.schedule
 
 
 def _mesh_average_impl(flat, world, group):
@@ -130,6 +162,8 @@ def _mesh_average_impl(flat, world, group):
 
 
 DataParallelSplat._mesh_average = lambda self, flat: _mesh_average_impl(flat, self.world, self.group)
+DataParallelSplat._average = _average_impl
+DataParallelSplat.tune_schedule = _tune_schedule_impl
 
 
 def reduce_metric(value, device=None, group=None):

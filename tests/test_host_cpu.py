@@ -167,17 +167,22 @@ loss.backward()
 for k in PARAM_ORDER:
     assert torch.allclose(getattr(m, k).grad, torch.full_like(getattr(m, k), mean)), k
 assert abs(reduce_metric(float(rank)) - (world - 1) / 2) < 1e-12
+if sys.argv[2] == "auto":      # tuned at the first exchange: a concrete schedule, the SAME one on every rank
+    assert dp.schedule in ("allreduce", "mesh") and set(dp.tuned_ms) == {"allreduce", "mesh"}
+    picks = [None] * world
+    dist.all_gather_object(picks, dp.schedule)
+    assert len(set(picks)) == 1, picks
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("schedule,world", [("allreduce", 2), ("mesh", 2), ("mesh", 3)])
+@pytest.mark.parametrize("schedule,world", [("allreduce", 2), ("mesh", 2), ("mesh", 3), ("auto", 2)])
 def test_data_parallel_gradient_path_gloo(tmp_path, schedule, world):
     """world 2 (and 3 for the mesh schedule: 14*50 gradients do not divide by 3, so its padded path runs)"""
     script = tmp_path / "dp_worker.py"
     script.write_text(_WORKER)
-    port = str(29611 + world + (10 if schedule == "mesh" else 0))
+    port = str(29611 + world + {"allreduce": 0, "mesh": 10, "auto": 20}[schedule])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, schedule],
