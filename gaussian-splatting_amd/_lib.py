@@ -14,6 +14,7 @@ SYMBOLS = [
     "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32",
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
     "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks",
+    "gsx_view_layout", "gsx_view_forward",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd", "gsx_image_loss_fwd_grad",
@@ -21,13 +22,19 @@ SYMBOLS = [
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
-ABI_VERSION = 9             # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 10            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
 TILE = 16
 CHUNK = 256
 STATE_WORDS = 8
+DEPTH_CHECK_BIT = 24        # GSX_DEPTH_CHECK_BIT
+# GSX_VIEW_* slots of gsx_constants.h (buffers of one view inside the arena of gsx_view_forward)
+VIEW_SLOT_NAMES = ("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state", "state",
+                   "total", "depth_keys", "pre", "keys_out", "keys_tmp", "values_tmp", "sort_ws", "tt_block_sums", "tile_box",
+                   "scan_ws", "tiles_tmp", "ranks_tmp", "bin_ws")
+VIEW_SLOTS = len(VIEW_SLOT_NAMES)
 
 
 class GsxError(RuntimeError):
@@ -68,6 +75,8 @@ def lib():
     L.gsx_bin_count.argtypes = [_p, _p, _i32, _p, _p, _p, _p, _sz, _p]
     L.gsx_bin_emit_sort.argtypes = [_p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32, _i32]
+    L.gsx_view_layout.restype = _i64; L.gsx_view_layout.argtypes = [_i32, _i32, _i32, _i64, _i32, _p, _p]
+    L.gsx_view_forward.argtypes = [_p] * 6 + [_i32, _i32, _i32, _i64, _i32, _p, _i32, _i32, _p, _i64] + [_p] * 6 + [_p, _p, _p]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
     L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
     L.gsx_preprocess_bwd.argtypes = [_p] * 12 + [_i32, _i32] + [_p] * 6
@@ -86,7 +95,7 @@ def lib():
     L.gsx_l1_ssim_bwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p, _p]
     for name in SYMBOLS:
         getattr(L, name)
-        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name != "gsx_max_chunks":
+        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name not in ("gsx_max_chunks", "gsx_view_layout"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

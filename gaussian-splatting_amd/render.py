@@ -6,6 +6,7 @@ Replaces GaussianSplat._forward_impl / _render_chunk and the autograd graph reco
 (/root/reference/model/gaussian_splatting.py:70-154, 188-344).
 """
 import ctypes as C
+import os
 import torch
 from . import _lib as L
 
@@ -67,6 +68,8 @@ class _Scratch:
     def __init__(self):
         self.capacity = {}
         self.pinned = {}
+        self.raw = {}
+        self.layouts = {}
         self.depth_bits = {}      # per device: key bits the next depth sort covers (24 while the top byte is constant)
         self.force_chunk = 0      # 64 / 128 / 256 pins the compositing chunk size (tests); 0 = the device picks it from D
 
@@ -89,6 +92,18 @@ class _Scratch:
         if key not in self.pinned:
             self.pinned[key] = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         return self.pinned[key]
+
+    def count_slot_raw(self, dev):
+        """(pinned, event, pinned address, raw hipEvent_t) -- gsx_view_forward records the event itself, in the middle of
+        its launches; torch creates the handle at the event's first record()"""
+        key = (dev, L.stream_ptr())
+        hit = self.raw.get(key)
+        if hit is None:
+            pinned, ev = self.count_slot(dev)
+            ev.record()
+            handle = ev.cuda_event
+            hit = self.raw[key] = (pinned, ev, pinned.data_ptr(), handle.value if hasattr(handle, "value") else int(handle))
+        return hit
 
 
 _scratch = _Scratch()
@@ -237,37 +252,133 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
     return rgb, alpha, dmap, state, chunk_state, max_chunks
 
 
+def _arena_shapes(n, H, W, cap, max_chunks):
+    tiles = ((W + L.TILE - 1) // L.TILE) * ((H + L.TILE - 1) // L.TILE)
+    i32, f32 = torch.int32, torch.float32
+    return {"order": (i32, (n,)), "rank_of": (i32, (n,)), "rec": (f32, (n, L.REC_FLOATS)), "tt": (i32, (n,)), "offsets": (i32, (n,)),
+            "tiles": (i32, (cap,)), "ranks": (i32, (cap,)), "ranges": (i32, (tiles, 2)), "chunk_base": (i32, (tiles + 2,)),
+            "chunk_state": (f32, (max(max_chunks, 1) * (L.STATE_WORDS * 256 + 12) + 16,)), "state": (i32, (4,))}
+
+
 class ViewState:
-    """Everything one view's backward needs (kept alive by the autograd node)."""
+    """Everything one view's backward needs (kept alive by the autograd node).  Either the buffers are separate tensors
+    (the stage-by-stage path) or they live in ONE block, `arena`, at the byte offsets `offs` gsx_view_layout gave: then a
+    field becomes a tensor view only when somebody asks for it (tests, tools), and the backward takes addresses."""
     __slots__ = ("pose", "order", "rank_of", "rec", "tt", "offsets", "ranks", "ranges", "chunk_base", "chunk_state", "max_chunks",
-                 "state", "D", "H", "W", "cap")
+                 "state", "D", "H", "W", "cap", "tiles", "arena", "offs", "n")
+
+    def __init__(self):
+        self.arena = None
+
+    def __getattr__(self, name):                      # reached only for a slot that holds nothing yet
+        arena = object.__getattribute__(self, "arena")
+        if arena is None or name not in _ARENA_FIELDS:
+            raise AttributeError(name)
+        dtype, shape = _arena_shapes(self.n, self.H, self.W, self.cap, self.max_chunks)[name]
+        count = 1
+        for d in shape:
+            count *= d
+        off = self.offs[name]
+        t = arena[off:off + 4 * count].view(dtype).view(shape)
+        setattr(self, name, t)
+        return t
+
+    def ptr(self, name):
+        """device address of a buffer, without materialising a tensor view for it"""
+        arena = self.arena
+        if arena is not None:
+            return arena.data_ptr() + self.offs[name]
+        return getattr(self, name).data_ptr()
+
+
+_ARENA_FIELDS = frozenset(("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state", "state"))
+
+# GSX_STAGED=1: render through the stage entry points (one allocation per buffer, one FFI call per stage) instead of
+# gsx_view_forward; a stage timer (bench.py's per-kernel HIP events) selects that path too.  Same launches either way.
+STAGED = os.environ.get("GSX_STAGED", "0") == "1"
 
 
 def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True):
     """One view. params = (positions, scales, rotations, opacity, features), fp32 contiguous CUDA."""
-    positions, scales, rotations, opacity, features = params
-    n = positions.shape[0]
-    mean2d, depth, cov2d, keys, pre = project(positions, scales, rotations, opacity, features, pose)
     # Binning and compositing are enqueued against the buffers' CAPACITY; the instance count D reaches the host
     # through pinned memory while the GPU is already sorting, so the stream never drains in the middle of a view
     # (gsx_bin_instances, the synchronising form, idles the GPU for ~0.1 ms per view).  If D exceeds the capacity
-    # -- first view of a scene, or a sudden jump -- the truncated results are discarded and the tail is redone.
+    # -- first view of a scene, or a sudden jump -- the truncated results are discarded and the view is redone.
     # The depth sort is optimistic in the same way: while the top byte of the depth keys is the same for every Gaussian
     # (depths within a binade or two, as in an orbit around a scene) it sorts on 24 bits, three passes instead of four;
     # the sort itself counts the keys that break the assumption, the count travels with D, and a view sorted on too few
     # bits is redone on all 32.
-    global _last_D
-    dev = pre.device
-    att = _enqueue_view(pre, keys, n, H, W, order, want_depth, need_bwd)
+    n = params[0].shape[0]
+    att = _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd)
     while not _check_view(att):
-        att = _enqueue_view(pre, keys, n, H, W, order, want_depth, need_bwd)
-    return _finish_view(att, pose, mean2d, depth, cov2d)
+        att = _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd)
+    return _finish_view(att, pose, att.mean2d, att.depth, att.cov2d)
+
+
+def _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd):
+    """One view enqueued, projection to compositing, instance count not yet looked at: through gsx_view_forward, or stage
+    by stage (GSX_STAGED=1, a stage timer, or an empty model)."""
+    if n > 0 and _timer is None and not STAGED:
+        return _enqueue_view_fused(params, pose, n, H, W, order, want_depth, need_bwd)
+    mean2d, depth, cov2d, keys, pre = project(*params, pose)
+    a = _enqueue_view(pre, keys, n, H, W, order, want_depth, need_bwd)
+    a.mean2d, a.depth, a.cov2d = mean2d, depth, cov2d
+    return a
 
 
 class _Attempt:
     """One enqueued view (everything after the projection) whose instance count the host has not looked at yet."""
     __slots__ = ("order", "rec", "tt", "rank_of", "offsets", "tiles", "ranks", "ranges", "chunk_base", "rgb", "alpha", "dmap", "state",
-                 "chunk_state", "max_chunks", "cap", "bits", "sorted_here", "pinned", "ev", "dev", "n", "H", "W", "D")
+                 "chunk_state", "max_chunks", "cap", "bits", "sorted_here", "pinned", "ev", "dev", "n", "H", "W", "D",
+                 "arena", "offs", "mean2d", "depth", "cov2d")
+
+    def __init__(self):
+        self.arena = None
+
+
+def _view_layout(n, H, W, cap, force):
+    key = (n, H, W, cap, force)
+    hit = _scratch.layouts.get(key)
+    if hit is None:
+        offs = (C.c_int64 * L.VIEW_SLOTS)(); mc = C.c_int64(0)
+        nbytes = int(L.lib().gsx_view_layout(n, H, W, cap, force, offs, C.byref(mc)))
+        if nbytes < 0:
+            raise L.GsxError(nbytes, "gsx_view_layout")
+        if len(_scratch.layouts) >= 64:
+            _scratch.layouts.clear()
+        hit = _scratch.layouts[key] = (nbytes, dict(zip(L.VIEW_SLOT_NAMES, (int(o) for o in offs))), int(mc.value))
+    return hit
+
+
+def _enqueue_view_fused(params, pose, n, H, W, given_order, want_depth, need_bwd):
+    """The whole view -- projection to compositing -- in ONE call over ONE block (gsx_view_forward): the same launches as
+    project() + _enqueue_view(), without their ~30 allocations and 7 FFI calls."""
+    a = _Attempt()
+    positions, scales, rotations, opacity, features = params
+    dev = a.dev = positions.device
+    a.n, a.H, a.W = n, H, W
+    a.sorted_here = given_order is None
+    a.bits = _scratch.depth_bits.get(dev, 32) if given_order is None else 32
+    if given_order is not None:
+        a.order = given_order
+    a.cap = _scratch.cap(dev, n)
+    force = _scratch.force_chunk
+    nbytes, a.offs, a.max_chunks = _view_layout(n, H, W, a.cap, force)
+    a.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    f32 = torch.float32
+    a.mean2d = torch.empty(n, 2, dtype=f32, device=dev)
+    a.depth = torch.empty(n, dtype=f32, device=dev)
+    a.cov2d = torch.empty(n, 2, 2, dtype=f32, device=dev)
+    a.rgb = torch.empty(3, H, W, dtype=f32, device=dev)
+    a.alpha = torch.empty(1, H, W, dtype=f32, device=dev)
+    a.dmap = torch.empty(1, H, W, dtype=f32, device=dev) if want_depth else None
+    a.pinned, a.ev, pinned_ptr, ev_handle = _scratch.count_slot_raw(dev)
+    L.check(L.lib().gsx_view_forward(positions.data_ptr(), scales.data_ptr(), rotations.data_ptr(), opacity.data_ptr(), features.data_ptr(),
+                                     pose.data_ptr(), n, H, W, a.cap, a.bits, _ptr(given_order), 1 if need_bwd else 0, force,
+                                     a.arena.data_ptr(), nbytes, a.mean2d.data_ptr(), a.depth.data_ptr(), a.cov2d.data_ptr(),
+                                     a.rgb.data_ptr(), a.alpha.data_ptr(), _ptr(a.dmap), pinned_ptr, ev_handle, _stream()),
+            "gsx_view_forward")
+    return a
 
 
 def _enqueue_view(pre, keys, n, H, W, given_order, want_depth, need_bwd):
@@ -304,21 +415,34 @@ def _check_view(a):
         raise L.GsxError(L.GSX_E_RANGE, "gsx_bin_emit_sort")
     if D > a.cap:
         redo = True
-        for k in ("tiles", "ranks", "ranges", "chunk_base", "rgb", "alpha", "dmap", "state", "chunk_state"):
+        for k in ("tiles", "ranks", "ranges", "chunk_base", "rgb", "alpha", "dmap", "state", "chunk_state", "arena"):
             setattr(a, k, None)                   # truncated results: release them before the buffers grow
         _scratch.grow(a.dev, D)
     return not redo
+
+
+class _LazyExtra:
+    """forward_view's third result: buffers only tests and tools look at ("tiles": the sorted tile ids)"""
+    def __init__(self, vs):
+        self._vs = vs
+
+    def __getitem__(self, name):
+        return getattr(self._vs, name)
 
 
 def _finish_view(a, pose, mean2d, depth, cov2d):
     global _last_D
     _last_D = a.D
     vs = ViewState()
-    vs.pose, vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = pose, a.order, a.rank_of, a.rec, a.tt, a.offsets
-    vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.max_chunks = a.ranks, a.ranges, a.chunk_base, a.chunk_state, a.max_chunks
-    vs.state, vs.D, vs.H, vs.W, vs.cap = a.state, a.D, a.H, a.W, a.cap
-    vs_extra = dict(tiles=a.tiles)
-    return (a.rgb, a.alpha, a.dmap, mean2d, depth, cov2d), vs, vs_extra
+    vs.pose, vs.max_chunks, vs.D, vs.H, vs.W, vs.cap, vs.n = pose, a.max_chunks, a.D, a.H, a.W, a.cap, a.n
+    if a.arena is not None:
+        vs.arena, vs.offs = a.arena, a.offs
+        if not a.sorted_here:
+            vs.order = a.order
+    else:
+        vs.order, vs.rank_of, vs.rec, vs.tt, vs.offsets = a.order, a.rank_of, a.rec, a.tt, a.offsets
+        vs.ranks, vs.ranges, vs.chunk_base, vs.chunk_state, vs.state, vs.tiles = a.ranks, a.ranges, a.chunk_base, a.chunk_state, a.state, a.tiles
+    return (a.rgb, a.alpha, a.dmap, mean2d, depth, cov2d), vs, _LazyExtra(vs)
 
 
 def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumulate):
@@ -332,13 +456,13 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
         # hands the block back instead of freeing and re-allocating tens of GB per view at config-5 scale
         partials = torch.empty(max(vs.D, getattr(vs, "cap", 0) or 0), 9, dtype=torch.float32, device=dev)
         with _stage("composite_bwd"):
-            L.check(lib.gsx_composite_bwd(_ptr(vs.rec), _ptr(vs.ranks), _ptr(vs.ranges), _ptr(vs.chunk_base), _ptr(vs.offsets),
-                                          n, vs.H, vs.W, vs.max_chunks, _ptr(vs.chunk_state), _ptr(vs.state),
+            L.check(lib.gsx_composite_bwd(vs.ptr("rec"), vs.ptr("ranks"), vs.ptr("ranges"), vs.ptr("chunk_base"), vs.ptr("offsets"),
+                                          n, vs.H, vs.W, vs.max_chunks, vs.ptr("chunk_state"), vs.ptr("state"),
                                           _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
     with _stage("preprocess_bwd"):
       L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations),
-                                   _ptr(vs.pose), _ptr(vs.rank_of), _ptr(vs.offsets), _ptr(vs.tt),
-                                   _ptr(partials), _ptr(vs.state), _ptr(d_mean2d), _ptr(d_depth), _ptr(d_cov2d),
+                                   _ptr(vs.pose), vs.ptr("rank_of"), vs.ptr("offsets"), vs.ptr("tt"),
+                                   _ptr(partials), vs.ptr("state"), _ptr(d_mean2d), _ptr(d_depth), _ptr(d_cov2d),
                                    n, 1 if accumulate else 0, *[_ptr(g) for g in grads], _stream()), "gsx_preprocess_bwd")
 
 
@@ -361,7 +485,7 @@ class RenderFunction(torch.autograd.Function):
         order = None
         for b in range(B):
             o, vs, _ = forward_view(params, poses[b], H, W, order=order, want_depth=want_depth, need_bwd=need_bwd)
-            if order is None:
+            if order is None and B > 1:
                 order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
             outs.append(o); views.append(vs)
         ctx.params, ctx.views, ctx.hw = params, views, (H, W)
@@ -436,10 +560,10 @@ def render_orbit(positions, scales, rotations, opacity, features, poses, image_s
     in_flight = []
 
     def retire(item):
-        v, s, att, pre, keys = item
+        v, s, att = item
         with torch.cuda.stream(s):
             while not _check_view(att):                       # rare: capacity or depth-sort width had to be corrected
-                att = _enqueue_view(pre, keys, n, H, W, None, False, False)
+                att = _enqueue_any(params, poses[v], n, H, W, None, False, False)
             global _last_D
             _last_D = att.D
             frames[v].copy_(att.rgb)
@@ -449,9 +573,8 @@ def render_orbit(positions, scales, rotations, opacity, features, poses, image_s
         with torch.cuda.stream(s):
             if v < S:
                 s.wait_event(start)                           # parameters and poses were produced on the caller's stream
-            _, _, _, keys, pre = project(*params, poses[v])
-            att = _enqueue_view(pre, keys, n, H, W, None, False, False)
-        in_flight.append((v, s, att, pre, keys))
+            att = _enqueue_any(params, poses[v], n, H, W, None, False, False)
+        in_flight.append((v, s, att))
         if len(in_flight) == S:
             retire(in_flight.pop(0))
     while in_flight:

@@ -483,3 +483,98 @@ def test_full_size_vs_oracle(dev, O, case):
     go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
     for k in PARAMS:
         assert rel_err(g[k], go[k]) < GRAD_RTOL, k
+
+
+# ---------------------------------------------------------------------------------------------
+# gsx_view_forward: one call over one arena == the stage entry points, bit for bit
+# ---------------------------------------------------------------------------------------------
+def _both_paths(monkeypatch, fn):
+    from gaussian_splatting_amd import render as R
+    monkeypatch.setattr(R, "STAGED", True); a = fn()
+    monkeypatch.setattr(R, "STAGED", False); b = fn()
+    return a, b
+
+
+@pytest.mark.parametrize("case", ["small_400x300", "c3_like_1024", "wide_1056x1040"])
+def test_view_driver_equals_stage_calls(dev, monkeypatch, case):
+    from gaussian_splatting_amd import render as R
+    if case == "small_400x300":
+        params, H, W, pose = default_scene(5000, 0), 300, 400, pose_tz(3.0)
+    elif case == "c3_like_1024":
+        params, H, W, pose = synth_scene(200000, 5, 0.001, 0.005), 1024, 1024, orbit_pose(10)
+    else:                                                    # > 4096 tiles: generic tile sort, no packed tile boxes
+        params, H, W, pose = synth_scene(20000, 9, 0.004, 0.03), 1040, 1056 * 4, pose_tz(2.0)
+    P = tuple(torch.from_numpy(np.ascontiguousarray(params[k], np.float32)).to(dev) for k in PARAMS)
+    pose_t = torch.from_numpy(np.ascontiguousarray(pose, np.float32)).to(dev)
+    d_rgb = torch.from_numpy(np.random.default_rng(1).standard_normal((3, H, W)).astype(np.float32)).to(dev)
+
+    def run():
+        R.forward_view(P, pose_t, H, W)                      # settles capacity and depth-sort width for this scene
+        outs, vs, extra = R.forward_view(P, pose_t, H, W)
+        grads = [torch.empty_like(p) for p in P]
+        R.backward_view(P, vs, d_rgb, None, None, None, grads, accumulate=False)
+        torch.cuda.synchronize()
+        D = vs.D
+        saved = dict(order=vs.order, rank_of=vs.rank_of, rec=vs.rec, tt=vs.tt, offsets=vs.offsets, tiles=extra["tiles"][:D],
+                     ranks=vs.ranks[:D], ranges=vs.ranges, chunk_base=vs.chunk_base, state=vs.state)
+        return outs, saved, grads, D, vs
+
+    (o1, s1, g1, D1, vs1), (o2, s2, g2, D2, vs2) = _both_paths(monkeypatch, run)
+    assert vs1.arena is None and vs2.arena is not None, "the second run went through gsx_view_forward"
+    assert D1 == D2 and D1 > 0
+    for a, b, name in zip(o1, o2, ("rgb", "alpha", "depth_map", "mean2d", "depth", "cov2d")):
+        assert torch.equal(a, b), name
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    for a, b, name in zip(g1, g2, PARAMS):
+        assert torch.equal(a, b), name
+        assert float(a.abs().max()) > 0
+
+
+def test_view_driver_batch_uses_first_views_order(dev, monkeypatch):
+    """B = 2 through the module: view 1 is composited in view 0's depth order (gaussian_splatting.py:206) on both paths"""
+    from gaussian_splatting_amd import GaussianSplat
+    params = synth_scene(3000, 4, 0.004, 0.03)
+    poses = torch.from_numpy(np.stack([pose_tz(2.0), pose_tz(2.5)])).to(dev)
+
+    def run():
+        m = GaussianSplat(3000)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        m = m.to(dev)
+        out = m(poses, (96, 128))
+        out["rendered_images"].square().sum().backward()
+        torch.cuda.synchronize()
+        return out["rendered_images"].detach().clone(), [getattr(m, k).grad.clone() for k in PARAMS]
+
+    (rgb1, g1), (rgb2, g2) = _both_paths(monkeypatch, run)
+    assert torch.equal(rgb1, rgb2)
+    for a, b, name in zip(g1, g2, PARAMS):
+        assert torch.equal(a, b), name
+
+
+def test_view_driver_rejects_bad_arguments(dev):
+    import ctypes as C
+    from gaussian_splatting_amd import _lib as L
+    lib = L.lib()
+    offs = (C.c_int64 * L.VIEW_SLOTS)(); mc = C.c_int64()
+    assert lib.gsx_view_layout(0, 64, 64, 1024, 0, offs, C.byref(mc)) == L.GSX_E_INVALID
+    assert lib.gsx_view_layout(10, 70000, 64, 1024, 0, offs, C.byref(mc)) == L.GSX_E_RANGE
+    nbytes = lib.gsx_view_layout(10, 64, 64, 1024, 0, offs, C.byref(mc))
+    assert nbytes > 0 and list(offs)[0] == 0 and all(o % 256 == 0 for o in offs) and mc.value == lib.gsx_max_chunks(1024, 64, 64, 0)
+    assert lib.gsx_view_layout(10, 64, 64, 1024, 0, None, None) == nbytes
+    arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    scene = synth_scene(10, 3, 0.01, 0.05)
+    p, sc, q, o, c = (torch.from_numpy(scene[k]).to(dev) for k in PARAMS)
+    pose = torch.from_numpy(pose_tz(2.0)).to(dev)
+    m2, d, cv, rgb, al = f(10, 2), f(10), f(10, 2, 2), f(3, 64, 64), f(1, 64, 64)
+    args = lambda ab: (p.data_ptr(), sc.data_ptr(), q.data_ptr(), o.data_ptr(), c.data_ptr(), pose.data_ptr(), 10, 64, 64, 1024, 32, None,
+                       1, 0, arena.data_ptr(), ab, m2.data_ptr(), d.data_ptr(), cv.data_ptr(), rgb.data_ptr(), al.data_ptr(), None,
+                       None, None, L.stream_ptr())
+    assert lib.gsx_view_forward(*args(nbytes - 1)) == L.GSX_E_CAPACITY          # block too small: nothing is launched
+    a = list(args(nbytes)); a[14] = arena.data_ptr() + 4
+    assert lib.gsx_view_forward(*a) == L.GSX_E_INVALID                          # misaligned block
+    a = list(args(nbytes)); a[10] = 0
+    assert lib.gsx_view_forward(*a) == L.GSX_E_INVALID                          # depth_bits out of range
+    assert lib.gsx_view_forward(*args(nbytes)) == L.GSX_OK
+    torch.cuda.synchronize()
