@@ -22,7 +22,7 @@ SYMBOLS = [
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
-ABI_VERSION = 10            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 12            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -31,8 +31,8 @@ CHUNK = 256
 STATE_WORDS = 8
 DEPTH_CHECK_BIT = 24        # GSX_DEPTH_CHECK_BIT
 # GSX_VIEW_* slots of gsx_constants.h (buffers of one view inside the arena of gsx_view_forward)
-VIEW_SLOT_NAMES = ("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state", "state",
-                   "total", "depth_keys", "pre", "keys_out", "keys_tmp", "values_tmp", "sort_ws", "tt_block_sums", "tile_box",
+VIEW_SLOT_NAMES = ("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state",
+                   "total", "partials", "depth_keys", "pre", "keys_out", "keys_tmp", "values_tmp", "sort_ws", "tt_block_sums", "tile_box",
                    "scan_ws", "tiles_tmp", "ranks_tmp", "bin_ws")
 VIEW_SLOTS = len(VIEW_SLOT_NAMES)
 
@@ -75,8 +75,8 @@ def lib():
     L.gsx_bin_count.argtypes = [_p, _p, _i32, _p, _p, _p, _p, _sz, _p]
     L.gsx_bin_emit_sort.argtypes = [_p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32, _i32]
-    L.gsx_view_layout.restype = _i64; L.gsx_view_layout.argtypes = [_i32, _i32, _i32, _i64, _i32, _p, _p]
-    L.gsx_view_forward.argtypes = [_p] * 6 + [_i32, _i32, _i32, _i64, _i32, _p, _i32, _i32, _p, _i64] + [_p] * 6 + [_p, _p, _p]
+    L.gsx_view_layout.restype = _i64; L.gsx_view_layout.argtypes = [_i32, _i32, _i32, _i64, _i32, _i32, _p, _p]
+    L.gsx_view_forward.argtypes = [_p] * 6 + [_i32, _i32, _i32, _i64, _i32, _p, _i32, _i32, _p, _i64] + [_p] * 7 + [_p, _p, _p]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
     L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
     L.gsx_preprocess_bwd.argtypes = [_p] * 12 + [_i32, _i32] + [_p] * 6

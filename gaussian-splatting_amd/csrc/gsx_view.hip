@@ -4,8 +4,12 @@
 // then pays an allocator call per buffer and an FFI call per stage -- about thirty of the former and seven of the
 // latter per view, ~0.2 ms of host time, which is what bounds a small scene (config 2: 0.31 ms of kernels).  Here the
 // caller allocates one block, gsx_view_layout says where each buffer lives in it, and gsx_view_forward enqueues the
-// same launches the stage entry points would, in the same order, on the same stream.  Host code only: no kernels of
-// its own, so results are the stage entry points' results bit for bit.
+// same launches the stage entry points would, in the same order, on the same stream.  The block starts with what the
+// backward reads later; behind that, the forward's scratch (sort ping-pong buffers, packed rows, workspaces) and the
+// backward's partial rows SHARE one region -- the scratch is dead once the forward's launches have run, the rows are
+// written only by the backward -- so a view costs one allocation of a size that repeats from step to step and nothing
+// is held twice (at config-5 scale the rows are ~90 GB and the scratch ~30 GB).
+// Host code only: no kernels of its own, so results are the stage entry points' results bit for bit.
 #include <hip/hip_runtime.h>
 #include "gsx_common.h"
 
@@ -19,7 +23,7 @@ struct Layout {
     int64_t bytes;
 };
 
-int make_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force, Layout& L)
+int make_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force, int32_t need_bwd, Layout& L)
 {
     if (N <= 0 || H <= 0 || W <= 0 || capacity <= 0) return GSX_E_INVALID;
     if (H > 65535 || W > 65535 || capacity >= 0xFFFFFFFFll) return GSX_E_RANGE;
@@ -40,9 +44,12 @@ int make_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk
     put(GSX_VIEW_RANGES, 8 * tiles);
     put(GSX_VIEW_CHUNK_BASE, 4 * (tiles + 2));
     put(GSX_VIEW_CHUNK_STATE, 4 * (int64_t)GSX_CHUNK_STATE_FLOATS(L.max_chunks > 0 ? L.max_chunks : 1));
-    put(GSX_VIEW_STATE, 16);
     put(GSX_VIEW_TOTAL, 16);
-    // dead once the forward's launches have run
+    // the shared tail: the backward's partial rows (one row of 9 floats per instance of capacity) ...
+    const int64_t tail = at;
+    L.off[GSX_VIEW_PARTIALS] = need_bwd ? tail : -1;
+    const int64_t partial_bytes = need_bwd ? align256(36 * capacity) : 0;
+    // ... over the forward's scratch, dead once its launches have run
     put(GSX_VIEW_DEPTH_KEYS, 4 * n);
     put(GSX_VIEW_PRE, 4 * GSX_REC_FLOATS * n);
     put(GSX_VIEW_KEYS_OUT, 4 * n);
@@ -56,17 +63,17 @@ int make_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk
     put(GSX_VIEW_RANKS_TMP, 4 * capacity);
     put(GSX_VIEW_BIN_WS, (int64_t)gsx_bin_workspace_bytes(N, capacity));
     if (!boxed) L.off[GSX_VIEW_TILE_BOX] = -1;
-    L.bytes = at;
+    L.bytes = tail + (at - tail > partial_bytes ? at - tail : partial_bytes);
     return GSX_OK;
 }
 
 }  // namespace
 
-GSX_API int64_t gsx_view_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force,
+GSX_API int64_t gsx_view_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force, int32_t need_bwd,
                                 int64_t* offsets_host, int64_t* max_chunks_host)
 {
     Layout L;
-    const int st = make_layout(N, H, W, capacity, chunk_force, L);
+    const int st = make_layout(N, H, W, capacity, chunk_force, need_bwd, L);
     if (st != GSX_OK) return st;
     if (offsets_host) for (int i = 0; i < GSX_VIEW_SLOTS; i++) offsets_host[i] = L.off[i];
     if (max_chunks_host) *max_chunks_host = L.max_chunks;
@@ -79,20 +86,20 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              const uint32_t* given_order, int32_t need_bwd, int32_t chunk_force,
                              void* arena, int64_t arena_bytes,
                              float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
-                             int64_t* D_pinned_host, void* count_event, void* stream)
+                             uint32_t* state, int64_t* D_pinned_host, void* count_event, void* stream)
 {
-    if (!positions || !scales || !rotations || !opacity || !features || !pose || !arena || !mean2d || !depth || !cov2d || !rgb || !alpha)
+    if (!positions || !scales || !rotations || !opacity || !features || !pose || !arena || !mean2d || !depth || !cov2d || !rgb || !alpha || !state)
         return GSX_E_INVALID;
     if (depth_bits <= 0 || depth_bits > 32 || ((uintptr_t)arena & 255u)) return GSX_E_INVALID;
     Layout L;
-    int st = make_layout(N, H, W, capacity, chunk_force, L);
+    int st = make_layout(N, H, W, capacity, chunk_force, need_bwd, L);
     if (st != GSX_OK) return st;
     if (arena_bytes < L.bytes) return GSX_E_CAPACITY;
-    char* base = static_cast<char*>(arena);
-    auto u32 = [&](int slot) { return L.off[slot] < 0 ? nullptr : reinterpret_cast<uint32_t*>(base + L.off[slot]); };
-    auto f32 = [&](int slot) { return reinterpret_cast<float*>(base + L.off[slot]); };
-    auto u64 = [&](int slot) { return reinterpret_cast<uint64_t*>(base + L.off[slot]); };
-    auto raw = [&](int slot) { return static_cast<void*>(base + L.off[slot]); };
+    auto at = [&](int slot) { return static_cast<char*>(arena) + L.off[slot]; };
+    auto u32 = [&](int slot) { return L.off[slot] < 0 ? nullptr : reinterpret_cast<uint32_t*>(at(slot)); };
+    auto f32 = [&](int slot) { return reinterpret_cast<float*>(at(slot)); };
+    auto u64 = [&](int slot) { return reinterpret_cast<uint64_t*>(at(slot)); };
+    auto raw = [&](int slot) { return static_cast<void*>(at(slot)); };
     uint64_t* total = u64(GSX_VIEW_TOTAL);
 
     st = gsx_project_fwd(positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d,
@@ -123,6 +130,6 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                            raw(GSX_VIEW_BIN_WS), gsx_bin_workspace_bytes(N, capacity), stream);
     if (st != GSX_OK) return st;
     return gsx_composite_fwd(f32(GSX_VIEW_REC), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), N, H, W,
-                             L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, u32(GSX_VIEW_STATE),
+                             L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, state,
                              rgb, alpha, depth_map, stream);
 }

@@ -13,7 +13,7 @@ from . import _lib as L
 
 def _ptr(t):
     # a plain int: ctypes converts it per argtypes; building a c_void_p object per argument was ~10 % of a step's host time
-    return None if t is None else t.data_ptr()
+    return t if (t is None or isinstance(t, int)) else t.data_ptr()
 
 
 _stream = L.stream_ptr
@@ -257,7 +257,7 @@ def _arena_shapes(n, H, W, cap, max_chunks):
     i32, f32 = torch.int32, torch.float32
     return {"order": (i32, (n,)), "rank_of": (i32, (n,)), "rec": (f32, (n, L.REC_FLOATS)), "tt": (i32, (n,)), "offsets": (i32, (n,)),
             "tiles": (i32, (cap,)), "ranks": (i32, (cap,)), "ranges": (i32, (tiles, 2)), "chunk_base": (i32, (tiles + 2,)),
-            "chunk_state": (f32, (max(max_chunks, 1) * (L.STATE_WORDS * 256 + 12) + 16,)), "state": (i32, (4,))}
+            "chunk_state": (f32, (max(max_chunks, 1) * (L.STATE_WORDS * 256 + 12) + 16,))}
 
 
 class ViewState:
@@ -286,12 +286,12 @@ class ViewState:
     def ptr(self, name):
         """device address of a buffer, without materialising a tensor view for it"""
         arena = self.arena
-        if arena is not None:
+        if arena is not None and name in _ARENA_FIELDS:
             return arena.data_ptr() + self.offs[name]
         return getattr(self, name).data_ptr()
 
 
-_ARENA_FIELDS = frozenset(("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state", "state"))
+_ARENA_FIELDS = frozenset(("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state"))
 
 # GSX_STAGED=1: render through the stage entry points (one allocation per buffer, one FFI call per stage) instead of
 # gsx_view_forward; a stage timer (bench.py's per-kernel HIP events) selects that path too.  Same launches either way.
@@ -336,12 +336,12 @@ class _Attempt:
         self.arena = None
 
 
-def _view_layout(n, H, W, cap, force):
-    key = (n, H, W, cap, force)
+def _view_layout(n, H, W, cap, force, need_bwd):
+    key = (n, H, W, cap, force, need_bwd)
     hit = _scratch.layouts.get(key)
     if hit is None:
         offs = (C.c_int64 * L.VIEW_SLOTS)(); mc = C.c_int64(0)
-        nbytes = int(L.lib().gsx_view_layout(n, H, W, cap, force, offs, C.byref(mc)))
+        nbytes = int(L.lib().gsx_view_layout(n, H, W, cap, force, 1 if need_bwd else 0, offs, C.byref(mc)))
         if nbytes < 0:
             raise L.GsxError(nbytes, "gsx_view_layout")
         if len(_scratch.layouts) >= 64:
@@ -363,7 +363,7 @@ def _enqueue_view_fused(params, pose, n, H, W, given_order, want_depth, need_bwd
         a.order = given_order
     a.cap = _scratch.cap(dev, n)
     force = _scratch.force_chunk
-    nbytes, a.offs, a.max_chunks = _view_layout(n, H, W, a.cap, force)
+    nbytes, a.offs, a.max_chunks = _view_layout(n, H, W, a.cap, force, bool(need_bwd))
     a.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     f32 = torch.float32
     a.mean2d = torch.empty(n, 2, dtype=f32, device=dev)
@@ -372,11 +372,13 @@ def _enqueue_view_fused(params, pose, n, H, W, given_order, want_depth, need_bwd
     a.rgb = torch.empty(3, H, W, dtype=f32, device=dev)
     a.alpha = torch.empty(1, H, W, dtype=f32, device=dev)
     a.dmap = torch.empty(1, H, W, dtype=f32, device=dev) if want_depth else None
+    # not in the block: callers keep it (the exit rank is one of forward()'s outputs) and must not pin the block with it
+    a.state = torch.empty(4, dtype=torch.int32, device=dev)
     a.pinned, a.ev, pinned_ptr, ev_handle = _scratch.count_slot_raw(dev)
     L.check(L.lib().gsx_view_forward(positions.data_ptr(), scales.data_ptr(), rotations.data_ptr(), opacity.data_ptr(), features.data_ptr(),
                                      pose.data_ptr(), n, H, W, a.cap, a.bits, _ptr(given_order), 1 if need_bwd else 0, force,
                                      a.arena.data_ptr(), nbytes, a.mean2d.data_ptr(), a.depth.data_ptr(), a.cov2d.data_ptr(),
-                                     a.rgb.data_ptr(), a.alpha.data_ptr(), _ptr(a.dmap), pinned_ptr, ev_handle, _stream()),
+                                     a.rgb.data_ptr(), a.alpha.data_ptr(), _ptr(a.dmap), a.state.data_ptr(), pinned_ptr, ev_handle, _stream()),
             "gsx_view_forward")
     return a
 
@@ -436,7 +438,7 @@ def _finish_view(a, pose, mean2d, depth, cov2d):
     vs = ViewState()
     vs.pose, vs.max_chunks, vs.D, vs.H, vs.W, vs.cap, vs.n = pose, a.max_chunks, a.D, a.H, a.W, a.cap, a.n
     if a.arena is not None:
-        vs.arena, vs.offs = a.arena, a.offs
+        vs.arena, vs.offs, vs.state = a.arena, a.offs, a.state
         if not a.sorted_here:
             vs.order = a.order
     else:
@@ -454,7 +456,10 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
     if d_rgb is not None and vs.D > 0:
         # sized by the buffers' capacity, not by this view's count: the same size every step, so torch's caching allocator
         # hands the block back instead of freeing and re-allocating tens of GB per view at config-5 scale
-        partials = torch.empty(max(vs.D, getattr(vs, "cap", 0) or 0), 9, dtype=torch.float32, device=dev)
+        if vs.arena is not None and vs.offs.get("partials", -1) >= 0:
+            partials = vs.arena.data_ptr() + vs.offs["partials"]        # `cap` rows, over the forward's dead scratch
+        else:
+            partials = torch.empty(max(vs.D, getattr(vs, "cap", 0) or 0), 9, dtype=torch.float32, device=dev)
         with _stage("composite_bwd"):
             L.check(lib.gsx_composite_bwd(vs.ptr("rec"), vs.ptr("ranks"), vs.ptr("ranges"), vs.ptr("chunk_base"), vs.ptr("offsets"),
                                           n, vs.H, vs.W, vs.max_chunks, vs.ptr("chunk_state"), vs.ptr("state"),

@@ -36,7 +36,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 10
+#define GSX_ABI_VERSION 12
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -158,15 +158,18 @@ int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint
  * gsx_view_layout: bytes of the block (or a negative GSX_E_*) for N Gaussians, an H x W image and instance buffers of
  *   `capacity`; offsets_host (nullable, GSX_VIEW_SLOTS entries, gsx_constants.h) receives each buffer's byte offset (-1:
  *   not present), *max_chunks_host (nullable) the chunk bound compositing is launched with (gsx_max_chunks(capacity, ...)).
- * gsx_view_forward: arena = that block (256-byte aligned, arena_bytes >= the layout's size).  depth_bits = 32, or
- *   GSX_DEPTH_CHECK_BIT if the previous view's mismatch count was 0 (see gsx_sort_pairs_u32); given_order (nullable) =
- *   a depth order to use instead of sorting (views after the first of a batch, :206).  The instance count D and the
- *   mismatch count land in arena[GSX_VIEW_TOTAL] (2 x u64) and, if D_pinned_host != NULL, in 16 bytes of pinned host
- *   memory; count_event (nullable hipEvent_t) is recorded right behind that copy, BEFORE binning and compositing are
- *   enqueued, so the host can learn D while the GPU is still busy with the view.  As with gsx_bin_emit_sort, D >
- *   capacity truncates the results (never out of bounds): the caller checks D and calls again with a larger block.
- *   Buffers GSX_VIEW_ORDER .. GSX_VIEW_TOTAL of the arena are what gsx_composite_bwd / gsx_preprocess_bwd need. */
-int64_t gsx_view_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force,
+ *   With need_bwd the block also holds the backward's partial rows (GSX_VIEW_PARTIALS, `capacity` rows of 9 floats, what
+ *   gsx_composite_bwd writes and gsx_preprocess_bwd sums) in the SAME region as the forward's scratch, which is dead by then.
+ * gsx_view_forward: arena = that block (256-byte aligned, arena_bytes >= the layout's size for the same arguments).
+ *   depth_bits = 32, or GSX_DEPTH_CHECK_BIT if the previous view's mismatch count was 0 (see gsx_sort_pairs_u32);
+ *   given_order (nullable) = a depth order to use instead of sorting (views after the first of a batch, :206).  The
+ *   instance count D and the mismatch count land in arena[GSX_VIEW_TOTAL] (2 x u64) and, if D_pinned_host != NULL, in
+ *   16 bytes of pinned host memory; count_event (nullable hipEvent_t) is recorded right behind that copy, BEFORE binning
+ *   and compositing are enqueued, so the host can learn D while the GPU is still busy with the view.  As with
+ *   gsx_bin_emit_sort, D > capacity truncates the results (never out of bounds): the caller checks D and calls again
+ *   with a larger block.  Buffers GSX_VIEW_ORDER .. GSX_VIEW_TOTAL are what gsx_composite_bwd / gsx_preprocess_bwd read;
+ *   `state` (gsx_composite_fwd's, 16 bytes) stays outside the block because callers keep it (the exit rank is an output). */
+int64_t gsx_view_layout(int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t chunk_force, int32_t need_bwd,
                         int64_t* offsets_host, int64_t* max_chunks_host);
 int gsx_view_forward(const float* positions, const float* scales, const float* rotations,
                      const float* opacity, const float* features, const float* pose,
@@ -174,7 +177,7 @@ int gsx_view_forward(const float* positions, const float* scales, const float* r
                      const uint32_t* given_order, int32_t need_bwd, int32_t chunk_force,
                      void* arena, int64_t arena_bytes,
                      float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
-                     int64_t* D_pinned_host, void* count_event, void* stream);
+                     uint32_t* state /* 4 x u32, as gsx_composite_fwd */, int64_t* D_pinned_host, void* count_event, void* stream);
 
 /* ---- backward of compositing (the reference relies on autograd over :124-144).  One wave64 per
  * chunk walks it back to front from the chunk-end state the forward left, reduces the nine

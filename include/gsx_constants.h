@@ -63,11 +63,14 @@
  * counts the keys that break that assumption (gsx_sort_pairs_u32's check_bit) */
 #define GSX_DEPTH_CHECK_BIT 24
 
-/* buffers of one view inside the arena of gsx_view_forward (indices into gsx_view_layout's offsets).  The first twelve
- * stay valid until the view's backward has run; the rest are scratch of the forward. */
+/* buffers of one view inside the block of gsx_view_forward (indices into gsx_view_layout's offsets).  GSX_VIEW_ORDER ..
+ * GSX_VIEW_TOTAL stay valid until the view's backward has run; GSX_VIEW_PARTIALS (the backward's rows: 9 floats per
+ * instance of capacity, present with need_bwd) starts where the forward's scratch (GSX_VIEW_DEPTH_KEYS on) starts: the two
+ * share that region, the scratch being dead once the forward's launches have run. */
 enum {
     GSX_VIEW_ORDER = 0, GSX_VIEW_RANK_OF, GSX_VIEW_REC, GSX_VIEW_TILES_TOUCHED, GSX_VIEW_OFFSETS, GSX_VIEW_TILES_SORTED,
-    GSX_VIEW_RANKS_SORTED, GSX_VIEW_RANGES, GSX_VIEW_CHUNK_BASE, GSX_VIEW_CHUNK_STATE, GSX_VIEW_STATE, GSX_VIEW_TOTAL,
+    GSX_VIEW_RANKS_SORTED, GSX_VIEW_RANGES, GSX_VIEW_CHUNK_BASE, GSX_VIEW_CHUNK_STATE, GSX_VIEW_TOTAL,
+    GSX_VIEW_PARTIALS,
     GSX_VIEW_DEPTH_KEYS, GSX_VIEW_PRE, GSX_VIEW_KEYS_OUT, GSX_VIEW_KEYS_TMP, GSX_VIEW_VALUES_TMP, GSX_VIEW_SORT_WS,
     GSX_VIEW_TT_BLOCK_SUMS, GSX_VIEW_TILE_BOX, GSX_VIEW_SCAN_WS, GSX_VIEW_TILES_TMP, GSX_VIEW_RANKS_TMP, GSX_VIEW_BIN_WS,
     GSX_VIEW_SLOTS

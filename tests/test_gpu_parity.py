@@ -557,24 +557,30 @@ def test_view_driver_rejects_bad_arguments(dev):
     from gaussian_splatting_amd import _lib as L
     lib = L.lib()
     offs = (C.c_int64 * L.VIEW_SLOTS)(); mc = C.c_int64()
-    assert lib.gsx_view_layout(0, 64, 64, 1024, 0, offs, C.byref(mc)) == L.GSX_E_INVALID
-    assert lib.gsx_view_layout(10, 70000, 64, 1024, 0, offs, C.byref(mc)) == L.GSX_E_RANGE
-    nbytes = lib.gsx_view_layout(10, 64, 64, 1024, 0, offs, C.byref(mc))
-    assert nbytes > 0 and list(offs)[0] == 0 and all(o % 256 == 0 for o in offs) and mc.value == lib.gsx_max_chunks(1024, 64, 64, 0)
-    assert lib.gsx_view_layout(10, 64, 64, 1024, 0, None, None) == nbytes
+    assert lib.gsx_view_layout(0, 64, 64, 1024, 0, 1, offs, C.byref(mc)) == L.GSX_E_INVALID
+    assert lib.gsx_view_layout(10, 70000, 64, 1024, 0, 1, offs, C.byref(mc)) == L.GSX_E_RANGE
+    nbytes = lib.gsx_view_layout(10, 64, 64, 1024, 0, 1, offs, C.byref(mc))
+    o = dict(zip(L.VIEW_SLOT_NAMES, offs))
+    assert nbytes > 0 and o["order"] == 0 and all(v % 256 == 0 for v in offs) and mc.value == lib.gsx_max_chunks(1024, 64, 64, 0)
+    assert o["partials"] == o["depth_keys"] > o["total"], "the backward's rows share the region of the forward's scratch"
+    assert nbytes >= o["partials"] + 36 * 1024 and nbytes > o["bin_ws"]
+    assert lib.gsx_view_layout(10, 64, 64, 1024, 0, 1, None, None) == nbytes
+    fwd_only = lib.gsx_view_layout(10, 64, 64, 1024, 0, 0, offs, C.byref(mc))
+    assert 0 < fwd_only <= nbytes and offs[L.VIEW_SLOT_NAMES.index("partials")] == -1
     arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
     scene = synth_scene(10, 3, 0.01, 0.05)
-    p, sc, q, o, c = (torch.from_numpy(scene[k]).to(dev) for k in PARAMS)
+    p, sc, q, op, c = (torch.from_numpy(scene[k]).to(dev) for k in PARAMS)
     pose = torch.from_numpy(pose_tz(2.0)).to(dev)
     m2, d, cv, rgb, al = f(10, 2), f(10), f(10, 2, 2), f(3, 64, 64), f(1, 64, 64)
-    args = lambda ab: (p.data_ptr(), sc.data_ptr(), q.data_ptr(), o.data_ptr(), c.data_ptr(), pose.data_ptr(), 10, 64, 64, 1024, 32, None,
-                       1, 0, arena.data_ptr(), ab, m2.data_ptr(), d.data_ptr(), cv.data_ptr(), rgb.data_ptr(), al.data_ptr(), None,
-                       None, None, L.stream_ptr())
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    args = lambda ab: [p.data_ptr(), sc.data_ptr(), q.data_ptr(), op.data_ptr(), c.data_ptr(), pose.data_ptr(), 10, 64, 64, 1024, 32,
+                       None, 1, 0, arena.data_ptr(), ab, m2.data_ptr(), d.data_ptr(), cv.data_ptr(),
+                       rgb.data_ptr(), al.data_ptr(), None, state.data_ptr(), None, None, L.stream_ptr()]
     assert lib.gsx_view_forward(*args(nbytes - 1)) == L.GSX_E_CAPACITY          # block too small: nothing is launched
-    a = list(args(nbytes)); a[14] = arena.data_ptr() + 4
+    a = args(nbytes); a[14] = arena.data_ptr() + 4
     assert lib.gsx_view_forward(*a) == L.GSX_E_INVALID                          # misaligned block
-    a = list(args(nbytes)); a[10] = 0
+    a = args(nbytes); a[10] = 0
     assert lib.gsx_view_forward(*a) == L.GSX_E_INVALID                          # depth_bits out of range
     assert lib.gsx_view_forward(*args(nbytes)) == L.GSX_OK
     torch.cuda.synchronize()
