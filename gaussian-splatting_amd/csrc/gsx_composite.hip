@@ -188,12 +188,15 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         if (threadIdx.x < 16) work[threadIdx.x] = 0u;
     }
     const uint32_t n_chunks = chunk_base[n_tiles];
-    if (blockIdx.x >= n_chunks) return;
-    const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
     uint32_t limit = N;
     if (PASS1) { limit = rank_limit_from_state(state, N); if (limit >= N) return; }
-    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
     const int lane = threadIdx.x;
+    // pass 0: one chunk per workgroup (gridDim.x >= n_chunks).  Pass 1 only has work after a global early exit, so it is
+    // launched with a small fixed grid -- an unsaturated view pays for a few hundred early returns, not for max_chunks of
+    // them -- and walks the chunks with a grid stride when it does run.
+    for (uint32_t blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
+    const uint32_t chunk = chunk_of_block(blk, n_chunks);
+    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
     const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
     float gx[2], gy[2];
     gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
@@ -265,6 +268,9 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
     const uint32_t gbits = (growth == 0.0f) ? 0u : (growth < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)growth + 2u : (uint32_t)GSX_META_GROWTH_MAX;
     if (lane == 0) chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT);
+    if (!PASS1) break;                        // compile-time: pass 0 has no back edge
+    __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -277,11 +283,13 @@ template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
-    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, uint32_t max_chunks,
+    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, uint32_t max_chunks, int n_tiles,
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
-    const int tile = blockIdx.x, pix = threadIdx.x;
+    const int pix = threadIdx.x;
+    // pass 0: one tile per workgroup; pass 1 (a no-op unless the global early exit fired): small grid, grid stride
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t c0 = chunk_base[tile], c1 = chunk_base[tile + 1];
     int x, y; pix_xy(pix >> 6, pix & 63, tile % tw, tile / tw, x, y);
     const bool inside = x < W && y < H;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                     const uint32_t meta = chunk_meta[c];
                     const uint32_t n_dark = (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]);
                     const uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * chunk size
-                    const uint32_t ch = chunk_base[gridDim.x + 1];                                                  // gridDim.x == n_tiles
+                    const uint32_t ch = chunk_base[n_tiles + 1];
                     cls = n_dark == 4u ? 4 : est >= 10u * ch ? 0 : est >= 6u * ch ? 1 : est >= 3u * ch ? 2 : 3;
                 }
                 const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
@@ -408,6 +416,9 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             }
         }
     }
+    if (!PASS1) break;                        // compile-time: pass 0 has no back edge
+    __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
-    int H, int W, int tw, float stepx, float stepy, uint32_t* __restrict__ state)
+    int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state)
 {
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(state, GSX_RANK_NONE);
         return;
     }
-    const int tile = blockIdx.x;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {     // small grid: this launch is a no-op on unsaturated views
     const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
     const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
     const bool inside = x < W && y < H;
@@ -460,6 +471,8 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(state, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+    __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -688,19 +701,21 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
+        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     } else {
         if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
+        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     }
-    saturation_rank_kernel<<<gt, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, sx, sy, state);
+    // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
+    const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
+    saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
-            chunk_fwd_kernel<true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-            tile_combine_kernel<true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
+            chunk_fwd_kernel<true, true><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
+            tile_combine_kernel<true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         } else {
-            chunk_fwd_kernel<true, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-            tile_combine_kernel<true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, rgb, alpha, depth_map);
+            chunk_fwd_kernel<true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
+            tile_combine_kernel<true, false><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         }
     }
     GSX_LAUNCH_CHECK();

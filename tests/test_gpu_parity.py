@@ -182,6 +182,9 @@ CASES = {
     "opacity_out_of_range": lambda: (synth_scene(3000, 9, 0.005, 0.03, o_lo=-0.5, o_hi=1.5), pose_tz(2.0), 96, 128),
     # 66 x 65 = 4290 tiles: beyond the one-pass 12-bit tile sort, i.e. the generic two-pass radix path + ranges kernel
     "more_than_4096_tiles_1056x1040": lambda: (synth_scene(4000, 12, 0.004, 0.03), pose_tz(2.0), 1040, 1056),
+    # every pixel saturates after a few screen-sized opaque splats: the reference's global early exit fires (n_composited < N)
+    # on 4096 tiles and > 2048 chunks, i.e. the exit search and the second compositing pass walk their small grids with a stride
+    "global_exit_4096_tiles": lambda: (synth_scene(400, 21, 1.0, 2.0, o_lo=0.9, o_hi=1.0), pose_tz(2.0), 1024, 1024),
     "empty_screen": lambda: (synth_scene(500, 10, 0.001, 0.002), _shifted_pose(50.0), 64, 64),   # D == 0
 }
 
@@ -201,6 +204,8 @@ def test_synthetic_vs_oracle(dev, O, case):
     assert np.array_equal(gp["cov2d"], fw["cov2d"], equal_nan=True)
     assert_integer_products_equal(gp, fw)
     assert gp["n_composited"] == fw["n_composited"]
+    if case.startswith("global_exit"):
+        assert fw["n_composited"] < params["positions"].shape[0] and fw["D"] > 2048 * 256
     assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
     assert np.abs(gp["alpha"] - fw["alpha"]).max() < RGB_TOL
     rng = np.random.default_rng(7)
