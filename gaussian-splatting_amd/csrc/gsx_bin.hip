@@ -8,7 +8,8 @@ namespace gsx {
 
 int sort_pairs_internal(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, const uint64_t*, int, int,
                         void*, size_t, hipStream_t, int check_bit = 32, uint64_t* mismatch_dev = nullptr);
-int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0);
+int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0,
+                  uint64_t* mirror = nullptr);
 size_t sort_ws_bytes_internal(int64_t n);
 
 // one thread per rank: write its tiles row-major at offsets[r]..  Writes stop at `capacity` (the caller finds
@@ -375,9 +376,18 @@ GSX_API int gsx_bin_count(const uint32_t* tiles_touched, const uint64_t* tt_bloc
     if (N < 0 || !total_dev) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (N > 0 && (!tiles_touched || !offsets || !ws || ws_bytes < gsx_scan_workspace_bytes(N))) return GSX_E_INVALID;
-    int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st, tt_block_sums, kBlock);     // N == 0: total = 0
+    // D and the caller's word reach the host from the scan kernel itself when the 16 bytes are pinned memory the device can
+    // address (hipHostMalloc / registered: what torch's pin_memory() gives) -- a hipMemcpyAsync of 16 bytes is a blit kernel,
+    // i.e. one more dependent launch (~4.5 us) in the middle of every view; anything else gets the copy
+    uint64_t* mirror = nullptr;
+    if (D_pinned_host && N > 0) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, D_pinned_host, 0) == hipSuccess) mirror = static_cast<uint64_t*>(dp);
+        else (void)hipGetLastError();
+    }
+    int s = scan_internal(tiles_touched, offsets, total_dev, N, ws, ws_bytes, st, tt_block_sums, kBlock, mirror);     // N == 0: total = 0
     if (s != GSX_OK) return s;
-    if (D_pinned_host) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 16, hipMemcpyDeviceToHost, st));   // D and the caller's word
+    if (D_pinned_host && !mirror) GSX_HIP(hipMemcpyAsync(D_pinned_host, total_dev, 16, hipMemcpyDeviceToHost, st));
     return GSX_OK;
 }
 

@@ -6,7 +6,8 @@
 
 namespace gsx {
 
-int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0);
+int scan_internal(const uint32_t*, uint32_t*, uint64_t*, int64_t, void*, size_t, hipStream_t, const uint64_t* block_sums = nullptr, int sums_tile = 0,
+                  uint64_t* mirror = nullptr);
 
 __global__ __launch_bounds__(kBlock) void keep_flags_kernel(const float* __restrict__ opacity, int N, float threshold,
                                                             uint32_t* __restrict__ keep)

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __r
 // third launch for the scan of the sums (a dependent launch costs ~4.6 us; at 1 M elements the table is 4 KB).  The
 // last workgroup also writes the grand total.
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
-                                                            const uint64_t* __restrict__ sums, int ratio, uint64_t* __restrict__ total)
+                                                            const uint64_t* __restrict__ sums, int ratio, uint64_t* __restrict__ total,
+                                                            uint64_t* __restrict__ mirror)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_pre[4];
@@ -92,7 +93,12 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
     uint32_t ex = ex0 + (uint32_t)pre;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) { int64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
-    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = pre + (uint64_t)tot;
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total = pre + (uint64_t)tot;
+        // mirror (nullable): two u64 of device-visible pinned HOST memory -- the total and the caller's word behind it go there
+        // straight from this kernel (a 16-byte hipMemcpyAsync is a blit kernel of its own: one more dependent launch)
+        if (mirror) { mirror[0] = pre + (uint64_t)tot; mirror[1] = total[1]; }
+    }
 }
 
 // one workgroup of 1024 threads scans up to kSmallScan values in a single launch (radix histograms of
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallScan = 8192;         // one sweep
 __global__ __launch_bounds__(kSmallThreads) void scan_small_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                                   int64_t n, uint64_t* __restrict__ total)
+                                                                   int64_t n, uint64_t* __restrict__ total, uint64_t* __restrict__ mirror)
 {
     __shared__ uint32_t s_w[kSmallThreads / 64];
     __shared__ uint64_t s_carry;                              // 64-bit so that *total is exact (prefixes wrap to u32)
@@ -125,30 +131,33 @@ __global__ __launch_bounds__(kSmallThreads) void scan_small_kernel(const uint32_
         if (threadIdx.x == kSmallThreads - 1) s_carry = wbase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total) *total = s_carry;
+    if (threadIdx.x == 0 && total) {
+        *total = s_carry;
+        if (mirror) { mirror[0] = s_carry; mirror[1] = total[1]; }
+    }
 }
 
 // block_sums (nullable): sums of consecutive groups of `sums_tile` elements that the producer of `in` already has
 // (build_records: one per 256 ranks); then the scan is ONE launch.
 static int scan_launch(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st,
-                       const uint64_t* block_sums = nullptr, int sums_tile = 0)
+                       const uint64_t* block_sums = nullptr, int sums_tile = 0, uint64_t* mirror = nullptr)
 {
     if (n <= kSmallScan && !block_sums) {
-        scan_small_kernel<<<dim3(1), dim3(kSmallThreads), 0, st>>>(in, out, n, total_dev);
+        scan_small_kernel<<<dim3(1), dim3(kSmallThreads), 0, st>>>(in, out, n, total_dev, mirror);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }
     int64_t nb = ceil_div(n, kScanTile);
     if (block_sums) {
         if (sums_tile <= 0 || kScanTile % sums_tile != 0) return GSX_E_INVALID;
-        scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, block_sums, kScanTile / sums_tile, total_dev);
+        scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, block_sums, kScanTile / sums_tile, total_dev, mirror);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }
     if (ws_bytes < (size_t)nb * 8) return GSX_E_CAPACITY;
     uint64_t* sums = (uint64_t*)ws;
     scan_reduce_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, n, sums);
-    scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, sums, 1, total_dev);
+    scan_apply_kernel<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(in, out, n, sums, 1, total_dev, mirror);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -352,13 +361,14 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
 }
 
 int scan_internal(const uint32_t* in, uint32_t* out, uint64_t* total_dev, int64_t n, void* ws, size_t ws_bytes, hipStream_t st,
-                  const uint64_t* block_sums, int sums_tile)
+                  const uint64_t* block_sums, int sums_tile, uint64_t* mirror)
 {
     if (n <= 0) {
         if (total_dev) GSX_HIP(hipMemsetAsync(total_dev, 0, 8, st));
+        if (total_dev && mirror) GSX_HIP(hipMemcpyAsync(mirror, total_dev, 16, hipMemcpyDeviceToHost, st));
         return GSX_OK;
     }
-    return scan_launch(in, out, total_dev, n, ws, ws_bytes, st, block_sums, sums_tile);
+    return scan_launch(in, out, total_dev, n, ws, ws_bytes, st, block_sums, sums_tile, mirror);
 }
 
 size_t sort_ws_bytes_internal(int64_t n) { return sort_ws_bytes(n); }
@@ -388,5 +398,5 @@ GSX_API int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* 
 {
     if (n < 0) return GSX_E_INVALID;
     if (n > 0 && (!in || !out_exclusive || !ws)) return GSX_E_INVALID;
-    return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
+    return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 0, nullptr);
 }

@@ -110,8 +110,9 @@ int gsx_bin_instances(const float* rec, const uint32_t* tiles_touched, int32_t N
  * forward (the synchronising read-back above idles the GPU for the length of a host round trip).
  * gsx_bin_count: offsets = exclusive scan of tiles_touched, total_dev[0] (device, u64) = instance count D;
  *   total_dev has TWO u64: [1] belongs to the caller (the render path parks the depth sort's mismatch count there).
- *   If D_pinned_host != NULL both words are also copied there asynchronously (16 bytes of pinned host memory; valid
- *   once the caller has synchronised on an event recorded after this call).  ws: gsx_scan_workspace_bytes(N).
+ *   If D_pinned_host != NULL both words also reach it asynchronously (16 bytes of pinned host memory; valid
+ *   once the caller has synchronised on an event recorded after this call): written by the scan kernel itself when the
+ *   device can address that memory (hipHostMalloc'ed or registered), copied with hipMemcpyAsync otherwise.  ws: gsx_scan_workspace_bytes(N).
  *   tt_block_sums: from gsx_build_records (the scan is then one launch), or NULL.
  * gsx_bin_emit_sort: everything after the count, with D read from *total_dev ON THE DEVICE and clamped to
  *   `capacity` (which sizes the launches): no host synchronisation.  If D turns out to exceed capacity the
