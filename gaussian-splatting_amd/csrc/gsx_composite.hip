@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t quad_mask(const float4& a, const float4& b, 
     const float k00 = a.z, kb = a.w, k11 = b.x;
     const bool proper = (k00 < 0.0f) && (k11 < 0.0f) && (4.0f * k00 * k11 - kb * kb > 0.0f);
     if (proper) {
-        const int e = (int)((__float_as_uint(b.y) >> 23) & 0xff) - 127;           // |o| < 2^(e+1)
+        const int e = max((int)((__float_as_uint(b.y) >> 23) & 0xff) - 127, GSX_CUT_MIN_EXP);           // |o| < 2^(e+1), floored like the box
         const float thr = -(float)(GSX_CUT_LOG2 + 1 + e) - 0.0625f;               // margin for rounding
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -379,8 +379,11 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         if (DEPTH) depth_map[p] = Dm;
     }
     if (!PASS1) {
-        // a pixel at least 1e-5 below the threshold is unsaturated in any arithmetic
-        const bool unsat = inside && !(A > GSX_SAT_ALPHA - 1e-5f);
+        // a pixel at least 1e-5 below the threshold is unsaturated in any arithmetic.  A NaN does not veto: it comes from a
+        // splat with exp2(q) = inf (a Gaussian at the camera plane: its 2x2 covariance is not positive definite) somewhere in
+        // the list, possibly BEHIND the rank at which the reference had already left its loop -- the exact search (F3) then
+        // decides with the reference's own arithmetic, and finds no exit if such a pixel never saturated before the NaN
+        const bool unsat = inside && (A <= GSX_SAT_ALPHA - 1e-5f);
         // thousands of tiles raise the same flag: look before the atomic (4096 same-address atomics serialise in L2)
         if (__syncthreads_or(unsat) && threadIdx.x == 0 &&
             __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(state + 1, 1u);

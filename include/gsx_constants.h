@@ -18,6 +18,11 @@
  * cut-off (dense evaluation, gaussian_splatting.py:118-144); 2^-24 keeps the dropped mass
  * far below the 1e-4 RGB tolerance. */
 #define GSX_CUT_LOG2 24
+/* ... with |opacity| taken as at least 2^(GSX_CUT_MIN_EXP + 1) = 2^-6 when the footprint is sized: d alpha / d opacity =
+ * exp(-q/2) does not shrink with the opacity, so a cut that followed |alpha| alone would eat the opacity gradient of a
+ * nearly transparent splat (at |o| = 1e-7 all but its core; at o = 0 everything, although the reference's gradient there
+ * is what lets such a splat come back).  With the floor every dropped pair has exp(-q/2) < 2^-18 whatever the opacity. */
+#define GSX_CUT_MIN_EXP (-7)
 /* 2*ln(2) rounded to float: kappa^2 = GSX_TWO_LN2 * (exponent(|o|) + 1 + GSX_CUT_LOG2) */
 #define GSX_TWO_LN2 1.3862944f
 

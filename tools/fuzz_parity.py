@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (dev tool, run on an MI355X): HIP path vs the CPU oracle on random small scenes -- sizes, image
+shapes (incl. 1-pixel rows / columns, non-multiples of 16), scale and opacity ranges, poses -- to the bars of the GPU tests
+(integer products bit-exact, RGB 1e-4, gradients 1e-3 relative).   python tools/fuzz_parity.py [cases] [first_seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import synth_scene, default_scene, pose_tz, orbit_pose, rel_err, PARAMS, RGB_TOL, GRAD_RTOL
+import test_gpu_parity as T
+from oracle import gsx_oracle as O
+from gaussian_splatting_amd import render as R
+
+O.lib()
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+t0 = time.time()
+for seed in range(first, first + cases):
+    g = np.random.default_rng(seed)
+    n = int(g.choice([1, 2, 7, 64, 300, 1000, 3000]))
+    H = int(g.choice([1, 2, 15, 16, 17, 33, 48, 100, 131, 256])); W = int(g.choice([1, 3, 16, 31, 64, 97, 160, 200, 333]))
+    lo = float(g.choice([0.001, 0.004, 0.02, 0.1])); hi = lo * float(g.choice([1.5, 5.0, 20.0]))
+    o_lo, o_hi = [(0.0, 1.0), (0.9, 1.0), (-0.5, 1.5), (0.0, 0.05), (1.0, 3.0)][int(g.integers(0, 5))]
+    zq = [None, None, 64.0][int(g.integers(0, 3))]
+    kind = int(g.integers(0, 3))
+    params = default_scene(n, seed) if kind == 0 else synth_scene(n, seed, lo, hi, zq=zq, o_lo=o_lo, o_hi=o_hi)
+    pose = pose_tz(float(g.choice([1.0, 2.0, 3.0, 6.0]))) if g.random() < 0.6 else orbit_pose(int(g.integers(0, 60)))
+    R._scratch.force_chunk = int(g.choice([0, 0, 64, 128, 256]))
+    tag = f"seed {seed}: n={n} {W}x{H} s=[{lo},{hi:.3g}] o=[{o_lo},{o_hi}] zq={zq} kind={kind} chunk={R._scratch.force_chunk}"
+    try:
+        gp = T.gpu_pipeline(params, pose, H, W, dev)
+        fw = O.forward(params, pose, H, W, "tiled")
+        assert np.array_equal(gp["mean2d"], fw["mean2d"], equal_nan=True), "mean2d"
+        assert np.array_equal(gp["depth"], fw["depth"], equal_nan=True), "depth"
+        T.assert_integer_products_equal(gp, fw)
+        assert gp["n_composited"] == fw["n_composited"], "exit index"
+        scale = max(1.0, float(np.nanmax(np.abs(fw["rgb"]), initial=0.0)))
+        assert np.array_equal(np.isnan(gp["rgb"]), np.isnan(fw["rgb"])), "NaN pixels differ"
+        assert np.nanmax(np.abs(gp["rgb"] - fw["rgb"]), initial=0.0) < RGB_TOL * scale, f"rgb {np.nanmax(np.abs(gp['rgb'] - fw['rgb']))}"
+        d_rgb = g.standard_normal((3, H, W)).astype(np.float32)
+        d_m = g.standard_normal((n, 2)).astype(np.float32); d_d = g.standard_normal(n).astype(np.float32)
+        d_c = g.standard_normal((n, 2, 2)).astype(np.float32)
+        gr = T.gpu_backward(gp, H, W, d_rgb, d_m, d_d, d_c)
+        go = O.backward(params, pose, H, W, fw, d_rgb, d_m, d_d, d_c, "tiled")
+        # a gradient tensor that is zero up to what the footprint cut may drop has no meaningful relative error: every dropped
+        # pair has exp(-q/2) < 2^-18 (gsx_constants.h), times an upstream gradient of order 1, summed over the pixels --
+        # floor the yardstick there (matters for 1-pixel-wide images whose only row lies in every splat's far tail)
+        floor = 2.0 ** -18 * H * W
+        for k in PARAMS:
+            if np.all(np.isfinite(go[k])):
+                err = float(np.abs(gr[k].astype(np.float64) - go[k]).max()) / max(float(np.abs(go[k]).max()), floor)
+                assert err < GRAD_RTOL, f"grad {k} {err}"
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", tag, "->", e, flush=True)
+    if (seed - first) % 25 == 24:
+        print(f"{seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+R._scratch.force_chunk = 0
+print(f"done: {cases} cases, {bad} failures")
+sys.exit(1 if bad else 0)
