@@ -39,10 +39,21 @@ for seed in range(first, first + cases):
         scale = max(1.0, float(np.nanmax(np.abs(fw["rgb"]), initial=0.0)))
         assert np.array_equal(np.isnan(gp["rgb"]), np.isnan(fw["rgb"])), "NaN pixels differ"
         assert np.nanmax(np.abs(gp["rgb"] - fw["rgb"]), initial=0.0) < RGB_TOL * scale, f"rgb {np.nanmax(np.abs(gp['rgb'] - fw['rgb']))}"
+        # the module's path (gsx_view_forward: one call, one block) against the stage calls above: same bits
+        t = gp["_t"]
+        (rgb_f, alpha_f, dmap_f, _, _, _), vs, _ = R.forward_view(t["P"], t["pose"], H, W)
+        assert vs.D == gp["D"], "fused D"
+        assert np.array_equal(rgb_f.cpu().numpy(), gp["rgb"], equal_nan=True) and np.array_equal(alpha_f.cpu().numpy()[0], gp["alpha"], equal_nan=True), "fused forward differs"
         d_rgb = g.standard_normal((3, H, W)).astype(np.float32)
         d_m = g.standard_normal((n, 2)).astype(np.float32); d_d = g.standard_normal(n).astype(np.float32)
         d_c = g.standard_normal((n, 2, 2)).astype(np.float32)
         gr = T.gpu_backward(gp, H, W, d_rgb, d_m, d_d, d_c)
+        cv = lambda a: torch.from_numpy(a).to(dev)
+        grads_f = [torch.empty_like(p) for p in t["P"]]
+        R.backward_view(t["P"], vs, cv(d_rgb), cv(d_m), cv(d_d), cv(d_c), grads_f, accumulate=False)
+        torch.cuda.synchronize()
+        for k, gf in zip(PARAMS, grads_f):
+            assert np.array_equal(gf.cpu().numpy(), gr[k], equal_nan=True), f"fused backward differs: {k}"
         go = O.backward(params, pose, H, W, fw, d_rgb, d_m, d_d, d_c, "tiled")
         # a gradient tensor that is zero up to what the footprint cut may drop has no meaningful relative error: every dropped
         # pair has exp(-q/2) < 2^-18 (gsx_constants.h), times an upstream gradient of order 1, summed over the pixels --
