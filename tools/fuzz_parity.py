@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (dev tool, run on an MI355X): HIP path vs the CPU oracle on random small scenes -- sizes, image
 shapes (incl. 1-pixel rows / columns, non-multiples of 16), scale and opacity ranges, poses -- to the bars of the GPU tests
-(integer products bit-exact, RGB 1e-4, gradients 1e-3 relative).   python tools/fuzz_parity.py [cases] [first_seed]"""
+(integer products bit-exact, RGB 1e-4, gradients 1e-3 relative).   python tools/fuzz_parity.py [cases] [first_seed] [big]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,13 +15,18 @@ O.lib()
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 bad = 0
 t0 = time.time()
 for seed in range(first, first + cases):
     g = np.random.default_rng(seed)
     n = int(g.choice([1, 2, 7, 64, 300, 1000, 3000]))
     H = int(g.choice([1, 2, 15, 16, 17, 33, 48, 100, 131, 256])); W = int(g.choice([1, 3, 16, 31, 64, 97, 160, 200, 333]))
+    if big:      # > 4096 tiles (generic tile sort + ranges kernel), and some with > 256 tiles a side (no packed tile boxes)
+        H = int(g.choice([1040, 1100, 1537, 2161])); W = int(g.choice([1056, 1920, 2500, 4200]))
     lo = float(g.choice([0.001, 0.004, 0.02, 0.1])); hi = lo * float(g.choice([1.5, 5.0, 20.0]))
+    if big:      # keep the CPU oracle to seconds per case: 3000 screen-sized splats on 17 k tiles are minutes
+        n = min(n, 1000); hi = min(hi, 0.2)
     o_lo, o_hi = [(0.0, 1.0), (0.9, 1.0), (-0.5, 1.5), (0.0, 0.05), (1.0, 3.0)][int(g.integers(0, 5))]
     zq = [None, None, 64.0][int(g.integers(0, 3))]
     kind = int(g.integers(0, 3))
@@ -66,7 +71,7 @@ for seed in range(first, first + cases):
     except AssertionError as e:
         bad += 1
         print("FAIL", tag, "->", e, flush=True)
-    if (seed - first) % 25 == 24:
+    if big or (seed - first) % 25 == 24:
         print(f"{seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
 R._scratch.force_chunk = 0
 print(f"done: {cases} cases, {bad} failures")
