@@ -690,7 +690,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
     if (!ranges || !chunk_base || !state || !rgb || !alpha) return GSX_E_INVALID;
-    if (max_chunks > 0 && (!rec || !ranks_sorted || !chunk_state)) return GSX_E_INVALID;
+    // an empty model (N == 0) has no records: every tile's list is empty, the chunk table says 0 chunks, nothing reads `rec`
+    if (max_chunks > 0 && ((N > 0 && !rec) || !ranks_sorted || !chunk_state)) return GSX_E_INVALID;
     if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;

@@ -638,3 +638,25 @@ def test_random_scenes_vs_oracle(dev, O):
     finally:
         R._scratch.force_chunk = 0
     assert not failures, failures
+
+
+def test_empty_and_tiny_models(dev):
+    """N = 0 (every tile list empty: a black image, empty per-Gaussian outputs, empty gradients), 1 and 2 through the module,
+    forward + backward + render_frames"""
+    from gaussian_splatting_amd import GaussianSplat
+    pose = torch.from_numpy(pose_tz(3.0))[None].to(dev)
+    for n in (0, 1, 2):
+        m = GaussianSplat(n).to(dev)
+        out = m(pose, (40, 56))
+        img = out["rendered_images"]
+        assert tuple(img.shape) == (1, 3, 40, 56) and tuple(out["positions"].shape) == (1, n, 2)
+        assert tuple(out["depths"].shape) == (1, n) and tuple(out["scales"].shape) == (1, n, 2, 2)
+        assert bool(torch.isfinite(img).all())
+        if n == 0:
+            assert float(img.detach().abs().sum()) == 0.0 and float(out["alpha"].detach().abs().sum()) == 0.0
+        (img.sum() + out["positions"].sum() + out["depths"].sum()).backward()
+        for k in PARAMS:
+            assert tuple(getattr(m, k).grad.shape) == tuple(getattr(m, k).shape), k
+        frames = m.render_frames(pose.repeat(3, 1, 1), (40, 56))
+        assert tuple(frames.shape) == (3, 3, 40, 56) and torch.equal(frames[0], img[0].detach())
+    torch.cuda.synchronize()
