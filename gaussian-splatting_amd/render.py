@@ -482,8 +482,11 @@ class RenderFunction(torch.autograd.Function):
             raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
                                "there is no CPU fallback")
         ctx.set_materialize_grads(False)
+        dev = positions.device
+        if not (scales.device == rotations.device == opacity.device == features.device == dev):
+            raise RuntimeError("gaussian-splatting_amd: the five parameter tensors must live on the same device")
         params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
-        poses = _f32c(poses.detach())
+        poses = _f32c(poses.detach().to(dev))          # a host pointer must never reach a kernel
         B = poses.shape[0]
         need_bwd = any(ctx.needs_input_grad[:5])
         outs, views = [], []

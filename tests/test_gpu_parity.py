@@ -417,6 +417,19 @@ def test_cpu_tensors_fail_loudly():
         m(torch.eye(4)[None], (8, 8))
 
 
+def test_host_poses_and_mixed_devices(dev):
+    """render_views called directly: poses on the host are moved (a host pointer must never reach a kernel), parameters on
+    different devices are refused"""
+    from gaussian_splatting_amd import GaussianSplat, render_views
+    m = GaussianSplat(50).to(dev)
+    pose_host = torch.from_numpy(pose_tz(3.0))[None]
+    a = render_views(m.positions, m.scales, m.rotations, m.opacity, m.features, pose_host, (24, 40))[0]
+    b = render_views(m.positions, m.scales, m.rotations, m.opacity, m.features, pose_host.to(dev), (24, 40))[0]
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        render_views(m.positions, m.scales.detach().cpu(), m.rotations, m.opacity, m.features, pose_host, (24, 40))
+
+
 def test_full_size_properties(dev):
     """BASELINE config 3/bench scene (1M Gaussians, 1024^2): size-independent properties."""
     params = synth_scene(1_000_000, 5, 0.001, 0.005)
