@@ -37,7 +37,7 @@ class _ImageLoss(torch.autograd.Function):
             raise RuntimeError("gaussian-splatting_amd.loss runs on an MI355X only (no CPU fallback); use torch ops on CPU tensors")
         lib = L.lib()
         p = pred.detach().contiguous().float()
-        t = target.detach().expand_as(pred).contiguous().float()
+        t = target.detach().to(pred.device).expand_as(pred).contiguous().float()      # a host pointer must never reach a kernel
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         wsb = lib.gsx_image_loss_workspace_bytes()
         ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
@@ -87,7 +87,7 @@ class _L1Ssim(torch.autograd.Function):
             raise ValueError("l1_ssim needs (..., H, W) images")
         lib = L.lib()
         p = pred.detach().contiguous().float()
-        t = target.detach().expand_as(pred).contiguous().float()
+        t = target.detach().to(pred.device).expand_as(pred).contiguous().float()      # a host pointer must never reach a kernel
         H, W = int(p.shape[-2]), int(p.shape[-1])
         planes = p.numel() // (H * W)
         loss3 = torch.empty(3, dtype=torch.float32, device=p.device)

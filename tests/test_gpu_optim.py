@@ -169,6 +169,15 @@ def test_config2_step_with_l1_ssim():
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), k
 
 
+def test_fused_losses_move_a_host_target():
+    from gaussian_splatting_amd import loss as gl
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.rand(1, 3, 20, 28, generator=g).to(dev); t = torch.rand(1, 3, 20, 28, generator=g)
+    assert float(gl.l1(x, t)) == float(gl.l1(x, t.to(dev)))
+    assert float(gl.l1_ssim(x, t)) == float(gl.l1_ssim(x, t.to(dev)))
+
+
 def test_fused_image_loss_rejects_cpu():
     from gaussian_splatting_amd import loss as gl
     with pytest.raises(RuntimeError):
