@@ -128,17 +128,23 @@ def _tune_schedule_impl(self, numel, device, reps=3):
     sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
     times = []
     for sched in ("allreduce", "mesh"):
-        self._average(buf, sched)
-        sync(); dist.barrier(group=self.group); sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        try:
             self._average(buf, sched)
-        sync()
-        times.append((time.perf_counter() - t0) / reps)
+            sync(); dist.barrier(group=self.group); sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self._average(buf, sched)
+            sync()
+            times.append((time.perf_counter() - t0) / reps)
+        except RuntimeError as e:          # a backend without all_to_all_single refuses on every rank alike: keep the all-reduce
+            if sched == "allreduce":
+                raise
+            self.tune_error = str(e).splitlines()[0][:200]
+            times.append(float("inf"))
     t = torch.tensor(times, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
     t = [float(x) for x in t.cpu()]
-    self.tuned_ms = {"allreduce": round(t[0] * 1e3, 4), "mesh": round(t[1] * 1e3, 4)}
+    self.tuned_ms = {"allreduce": round(t[0] * 1e3, 4), "mesh": round(t[1] * 1e3, 4) if t[1] != float("inf") else None}
     self.schedule = "allreduce" if t[0] <= t[1] else "mesh"
     return self.schedule
 
