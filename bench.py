@@ -3,47 +3,64 @@
 configuration: 1M Gaussians, 1024x1024, the 60-view orbit of config 3 (SURVEY 8d seed 5).
 
     python bench.py --gpus 1 --steps 60 --warmup 5
+    python bench.py --gpus N ...          # no torchrun environment: spawns its N ranks itself (as child processes,
+                                          # before anything touches a GPU) and exits with their status
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --backend gloo     # rehearsal of the N>1 path on ONE GPU (ranks share the card, gloo exchange)
 
 A "step" is one trainer step on one view per GPU (trainer.py:134-175 sequence): zero_grad ->
 render forward -> L1 loss -> render backward -> [N>1: one RCCL all-reduce of the flat 14*N
-gradient buffer, or the all-to-all + all-gather mesh schedule if that timed faster at start-up] -> clip_grad_norm_(0.1) -> Adam step.  View of rank r at step s is
-(s*N + r) mod 60: views are sharded over GPUs, per-GPU work is fixed (weak scaling).
+gradient buffer, or the all-to-all + all-gather mesh schedule if that timed faster at start-up] -> clip_grad_norm_(0.1) -> Adam step.
+View of rank r at step s is ((s*N + r) * 7) mod 60: views are sharded over GPUs, per-GPU work is fixed (weak scaling),
+and the stride (7 is coprime with 60) makes ANY window of steps a sample of the whole orbit -- the orbit's views differ 2x
+in instance count, so walking them in order made the value depend on which stretch `--steps` happened to time.
 value = N * K * H * W / max-over-ranks wall time / 1e6 (Mpix/s), inputs resident in HBM.
 
 Rank 0 also reports (same JSON line):
-  roofline      dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
-  cpu_baseline  the CPU oracle (tiled restatement, "port") timed on the host for ONE view
+  roofline         dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline     the CPU oracle (tiled restatement, "port") timed on the host on a few views of the same workload,
+                   the same step (render fwd + L1 + bwd + clip + Adam)
+  cpu_baseline_c1  BASELINE.md row CPU-A: the reference ALGORITHM (dense restatement: every Gaussian x every pixel, global
+                   early exit) at config 1 (5000 Gaussians, 400x300) on the same host
+  rccl             N>1 (or --force-dp): backend, world size seen by torch.distributed, bytes per exchange, and the
+                   exchange's duration from HIP events around it inside the timed loop
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
-# stage -> kernel whose PMC traffic (profiles/r1_pmc_hbm_traffic.json, separate rocprofv3 --pmc passes) belongs to it
-STAGE_KERNEL = {"composite_bwd": "gsx::chunk_bwd_kernel", "composite_fwd": "gsx::chunk_fwd_kernel<false, true>",
-                "preprocess_bwd": "gsx::preprocess_bwd_kernel", "build_records": "gsx::build_records_kernel",
-                "project_fwd": "gsx::project_fwd_kernel"}
+PMC_FILE = os.path.join("profiles", "r2_pmc_hbm_traffic.json")
+# stage -> substring of the kernel name whose PMC traffic (separate rocprofv3 --pmc passes, tools/pmc_traffic.py) belongs to it
+STAGE_KERNEL = {"composite_bwd": "chunk_bwd_kernel", "composite_fwd": "chunk_fwd_kernel<false, false>",
+                "preprocess_bwd": "preprocess_bwd_kernel", "build_records": "build_records_kernel",
+                "project_fwd": "project_fwd_kernel"}
+N_VIEWS = 60
+VIEW_STRIDE = 7
 
 
 def pmc_traffic_bytes(stage):
     """HBM bytes per launch of the stage's kernel from the committed PMC summary (None if absent)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
-            k = json.load(f)["kernels"][STAGE_KERNEL[stage]]
-        return int(k["hbm_total_MB"] * 1024 * 1024)
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            kernels = json.load(f)["kernels"]
+        want = STAGE_KERNEL[stage]
+        for name, k in kernels.items():
+            if want in name:
+                return int(k["hbm_total_MB"] * 1024 * 1024)
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def algorithmic_bytes(stage, n, d, p):
@@ -61,6 +78,90 @@ def algorithmic_bytes(stage, n, d, p):
     }[stage]
 
 
+def view_of(step, rank, world):
+    return ((step * world + rank) * VIEW_STRIDE) % N_VIEWS
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torch.distributed.run and hand its exit
+    status on.  Nothing in this process has touched a GPU (a process that has must not be replaced or forked into ranks)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        print(f"[bench] a rank failed: torch.distributed.run exited with {r.returncode}", file=sys.stderr)
+    return r.returncode
+
+
+def cpu_baselines(args, params, H, W, target_np):
+    """The two CPU rows of BASELINE.md section 3, on this host's cores (rank 0, N = 1 only)."""
+    import torch
+    from oracle import gsx_oracle as O          # checker / reported baseline only
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.scenes import create_orbit_poses, pose_tz
+    from gaussian_splatting_amd.trainer import DEFAULT_LRS
+    O.lib()
+    names = ("positions", "scales", "rotations", "opacity", "features")
+
+    def host_step(p, pose, h, w, target, mode, adam):
+        """one trainer step on the host: render fwd, L1, render bwd, clip_grad_norm_(0.1), Adam"""
+        fw = O.forward(p, pose, h, w, mode)
+        d_rgb = (np.sign(fw["rgb"] - target) / target.size).astype(np.float32)
+        g = O.backward(p, pose, h, w, fw, d_rgb, None, None, None, mode)
+        total = np.sqrt(sum(float((g[k] ** 2).sum()) for k in names))
+        coef = min(1.0, 0.1 / (total + 1e-6))
+        adam["t"] += 1
+        t = adam["t"]
+        for k in names:
+            gk = (g[k] * coef).astype(np.float32).reshape(p[k].shape)
+            m = adam.setdefault("m" + k, np.zeros_like(p[k])); v = adam.setdefault("v" + k, np.zeros_like(p[k]))
+            m *= 0.9; m += 0.1 * gk
+            v *= 0.999; v += 0.001 * gk * gk
+            p[k] -= DEFAULT_LRS[k] * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
+        return fw
+
+    # CPU-B: the tiled restatement on a bounded sample of the bench workload
+    all_poses = create_orbit_poses(4.0, N_VIEWS, 45.0)
+    p = {k: v.copy() for k, v in params.items()}
+    sample_views, ds, adam = (10, 30, 50), [], {"t": 0}
+    t1 = time.perf_counter()
+    for v in sample_views:                         # ~4 s of 16-thread CPU work per view
+        ds.append(int(host_step(p, all_poses[v], H, W, target_np, "tiled", adam)["D"]))
+    tc = time.perf_counter() - t1
+    cpu = {"value": round(len(sample_views) * H * W / tc / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(), "kind": "port",
+           "includes": ["render_fwd", "l1_loss", "render_bwd", "clip_grad_norm", "adam"], "like_for_like_with_value": True,
+           "sample": f"{len(sample_views)} trainer steps (orbit views {sample_views}, D={ds}) of the same workload on the tiled CPU "
+                     f"restatement, {tc:.2f} s; the reference's own dense loop cannot run at this size (16 ns*N*P, SURVEY 6)"}
+
+    # CPU-A: the reference algorithm itself (dense, global early exit) at config 1 -- same seeded init as the reference's
+    # `torch.manual_seed(0); GaussianSplat(5000)`, pose = I with t_z = 3 (BASELINE.md section 2)
+    torch.manual_seed(0)
+    m1 = GaussianSplat(5000)
+    p1 = {k: getattr(m1, k).detach().numpy().copy() for k in names}
+    h1, w1 = 300, 400
+    tgt1 = np.random.default_rng(1).random((3, h1, w1), dtype=np.float32)
+    times, k_exit = [], None
+    for i in range(4):                             # 1 warm-up + 3 timed
+        q = {k: v.copy() for k, v in p1.items()}
+        t1 = time.perf_counter()
+        fw = host_step(q, pose_tz(3.0), h1, w1, tgt1, "dense", {"t": 0})
+        if i:
+            times.append(time.perf_counter() - t1)
+        k_exit = int(fw["n_composited"])
+    med = sorted(times)[len(times) // 2]
+    c1 = {"value": round(h1 * w1 / med / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(), "kind": "port",
+          "algorithm": "dense (the reference's: every Gaussian x every pixel, global early exit)",
+          "sample": f"config 1: 5000 Gaussians (reference init, seed 0), 400x300, one trainer step, median of {len(times)}: {med:.3f} s; "
+                    f"early exit after {k_exit} Gaussians",
+          "true_reference_measured_in_survey": {"value": 0.0126, "unit": "Mpix/s", "cores": 8,
+                                                "note": "BASELINE.md section 2: the reference's PyTorch loop, fwd+bwd 9.54 s, survey container"}}
+    return cpu, c1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +176,9 @@ def main():
                     help="informational: forward-only orbit rendering (SURVEY 8f N1, render_frames); not the headline metric")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the multi-GPU path on one GPU: init RCCL with world 1 and run the collectives anyway")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend for N>1: nccl (= RCCL, one rank per GPU) or gloo (rehearsal: the ranks may "
+                         "share a GPU, gradients are exchanged through the host)")
     ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh", "auto"),
                     help="gradient exchange: one RCCL all-reduce (default), all-to-all + local sum + all-gather (SURVEY 8e's mesh "
                          "schedule), or auto = time both on a scratch buffer at the first exchange and keep the faster")
@@ -82,19 +186,30 @@ def main():
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        sys.exit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        sys.exit(f"bench.py --gpus {world} needs {world} GPUs for RCCL, this node shows {n_dev} (--backend gloo rehearses on fewer)")
+    local_dev = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1 or args.force_dp:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from gaussian_splatting_amd import GaussianSplat
     from gaussian_splatting_amd import render as R
@@ -114,18 +229,16 @@ def main():
     schedule = args.dp_schedule or os.environ.get("GSX_DP_SCHEDULE", "auto")
     net = DataParallelSplat(model, force_collectives=args.force_dp, schedule=schedule) if use_dp else model
     if use_dp and net.schedule == "auto":
-        net.tune_schedule(14 * n, dev)
+        net.tune_schedule(14 * n + R.GRAD_TAIL, dev)
     opt = make_optimizer(net, fused_clip_norm=None if args.torch_optimizer else 0.1)
-    n_views = 60
-    poses = torch.from_numpy(create_orbit_poses(4.0, n_views, 45.0)).to(dev)      # README.md:129-137
+    poses = torch.from_numpy(create_orbit_poses(4.0, N_VIEWS, 45.0)).to(dev)      # README.md:129-137
     g = torch.Generator(device="cpu").manual_seed(3)
-    target = torch.rand(1, 3, H, W, generator=g).to(dev)
+    target_cpu = torch.rand(1, 3, H, W, generator=g)
+    target = target_cpu.to(dev)
 
     def step(s):
-        v = (s * world + rank) % n_views
-        if args.inference:
-            raise RuntimeError("inference steps go through orbit_pass()")
-        elif args.no_optimizer:
+        v = view_of(s, rank, world)
+        if args.no_optimizer:
             opt.zero_grad()
             out = net(poses[v:v + 1], (H, W))
             loss_fn(out, target).backward()
@@ -140,14 +253,14 @@ def main():
 
     def orbit_pass(first, count):
         """forward-only: `count` views of this rank's share of the orbit in ONE render_frames call (views pipelined over streams)"""
-        idx = torch.tensor([((first + i) * world + rank) % n_views for i in range(count)], device=dev)
+        idx = torch.tensor([view_of(first + i, rank, world) for i in range(count)], device=dev)
         model.render_frames(poses[idx], (H, W))
 
     def run(first, count):
         if args.inference:
             done = 0
             while done < count:
-                k = min(n_views, count - done)
+                k = min(N_VIEWS, count - done)
                 orbit_pass(first + done, k); done += k
         else:
             for s in range(count):
@@ -155,10 +268,16 @@ def main():
 
     run(0, args.warmup)
     fence()
+    if use_dp:
+        net.time_exchange = True                  # two HIP events per exchange, read after the timed region
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
+    exchange_ms = None
+    if use_dp:
+        net.time_exchange = False
+        exchange_ms = net.exchange_ms()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,71 +290,69 @@ def main():
     timer = R.StageTimer() if rank == 0 else None
     R.set_stage_timer(timer)
     d_sum = 0
-    k_prof = 0 if args.inference else min(args.steps, n_views)
+    k_prof = 0 if args.inference else min(args.steps, N_VIEWS)
     for s in range(k_prof):
-        v = (s * world + rank) % n_views
+        v = view_of(args.warmup + s, rank, world)     # the views the timed region rendered
         opt.zero_grad()
         out = net(poses[v:v + 1], (H, W))
         d_sum += R.last_instance_count()
         loss_fn(out, target).backward()
     R.set_stage_timer(None)
     fence()
+    d_avg = d_sum / k_prof if k_prof else 0
     if rank == 0 and k_prof:
         tot = timer.totals_ms()
-        d_avg = d_sum / k_prof
         stages = {k: round(t / c, 4) for k, (t, c) in tot.items()}
         dom = max(("composite_fwd", "composite_bwd", "depth_sort", "bin_instances", "project_fwd", "build_records",
                    "preprocess_bwd"), key=lambda k: stages.get(k, 0.0))
         alg = algorithmic_bytes(dom, n, d_avg, H * W)
         ach = alg / (stages[dom] * 1e-3) / 1e9
+        traffic = pmc_traffic_bytes(dom) if args.config == "c3" else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_bytes(dom) if args.config == "c3" else None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_missing": traffic is None,
                     "algorithmic_bytes_per_launch": int(alg),
                     "avg_launch_ms": stages[dom], "avg_instances_D": int(d_avg),
-                    "note": "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                            "(profiles/r1_pmc_hbm_traffic.json; reads x2 as the gfx950 guide prescribes). The kernel is "
-                            "VALU-issue bound (85% of the chip's VALU issue slots, SQ counters in profiles/r1_pmc_sq_counters.json, "
+                    "note": f"traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                            f"({PMC_FILE}; reads x2 as the gfx950 guide prescribes; c3 only). The kernel is "
+                            "VALU-issue bound (SQ counters in profiles/r2_pmc_sq_counters.json, "
                             "DESIGN.md 4): its HBM fraction is small by construction"}
 
-    cpu = None
+    cpu = cpu_c1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # N=1 only: the other ranks would sit in the teardown meanwhile
-        from oracle import gsx_oracle as O          # checker / reported baseline only
-        O.lib()
-        all_poses = create_orbit_poses(4.0, n_views, 45.0)
-        d_rgb = np.sign(np.random.default_rng(1).standard_normal((3, H, W))).astype(np.float32) / (3 * H * W)
-        sample_views, ds = (10, 30, 50), []
-        t1 = time.perf_counter()
-        for v in sample_views:                         # ~4 s of 16-thread CPU work per view
-            fw = O.forward(params, all_poses[v], H, W, "tiled")
-            O.backward(params, all_poses[v], H, W, fw, d_rgb, None, None, None, "tiled")
-            ds.append(int(fw["D"]))
-        tc = time.perf_counter() - t1
-        cpu = {"value": round(len(sample_views) * H * W / tc / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(), "kind": "port",
-               "sample": f"{len(sample_views)} views (orbit views {sample_views}, D={ds}) of the same workload, tiled CPU restatement "
-                         f"fwd+bwd (render only, no loss/optimizer), {tc:.2f} s; the reference's own dense loop cannot run at this "
-                         "size (16 ns*N*P, SURVEY 6)"}
+        cpu, cpu_c1 = cpu_baselines(args, params, H, W, target_cpu[0].numpy())
+
+    rccl = None
+    if use_dp:
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "device": str(dev), "gpu": torch.cuda.get_device_name(dev)})
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks": seen,
+                "bytes_per_exchange": net.last_allreduce_bytes, "zero_copy_flat_buffer": net.last_sync_was_flat,
+                "schedule": net.schedule, "exchange_ms_on_scratch": net.tuned_ms,
+                "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
+                "exchange_ms_note": "mean over the timed steps, HIP events around the collective on rank 0's stream"}
 
     if rank == 0:
         value = world * args.steps * H * W / dt / 1e6
+        timed_views = [view_of(args.warmup + s, 0, world) for s in range(args.steps)]
         line = {
             "metric": ("forward-only (inference) " if args.inference else "fwd+bwd ") + "splat-render Mpixels/s "
                       + ("@1M Gaussians 1024^2" if args.config == "c3" else f"@{n} Gaussians {W}x{H} (not the headline configuration)"),
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ns_per_instance": round(dt / args.steps * 1e9 / d_avg, 4) if d_avg else None,
             "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, 60-view orbit (radius 4, elevation 45), "
                                    f"one trainer step per view per GPU"
                                    + (" (INFERENCE: forward only, not the headline metric)" if args.inference else " (render fwd+bwd only)" if args.no_optimizer else (f" (fwd + {args.loss.upper()} + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
                                       else f" (fwd + {args.loss.upper()} + bwd + fused clip_grad_norm+Adam)")),
                        "views_per_step": world, "parallelism": f"dp{world} over views",
-                       **({"gradient_exchange": net.schedule, "exchange_ms_on_scratch": net.tuned_ms} if use_dp else {})},
-            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
+                       "view_order": f"rank r, step s -> orbit view ((s*{world} + r) * {VIEW_STRIDE}) mod {N_VIEWS}",
+                       "views_timed_rank0": {"count": len(timed_views), "distinct": len(set(timed_views)), "first": timed_views[:8]},
+                       **({"gradient_exchange": net.schedule} if use_dp else {})},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "rccl": rccl, "stage_ms": stages,
         }
         print(json.dumps(line), flush=True)
     if use_dp:
-        if rank == 0:
-            print(f"[bench] gradient all-reduce: {net.last_allreduce_bytes} B per step, "
-                  f"zero-copy flat buffer: {net.last_sync_was_flat}", file=sys.stderr)
         dist.destroy_process_group()
 
 

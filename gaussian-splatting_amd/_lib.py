@@ -101,14 +101,57 @@ def lib():
     return L
 
 
-def stream_ptr():
-    """torch's current HIP stream on the current device as an integer handle (the raw-handle getters are ~20x cheaper than
-    torch.cuda.current_stream(), which a trainer step would otherwise call a dozen times)."""
+# The three torch hooks the binding needs, behind module-level names so that host-side tests can replace them (no GPU
+# in the CPU suite).  All are raw-handle getters: ~20x cheaper than torch.cuda.current_stream() / torch.cuda.device().
+def _cur_device():
     import torch
-    try:
-        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())      # an int: converted per argtypes
-    except AttributeError:
-        return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getDevice()
+
+
+def _exchange_device(index):
+    """make `index` the current device -> the previous one"""
+    import torch
+    return torch._C._cuda_exchangeDevice(index)
+
+
+def _raw_stream(index):
+    import torch
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+def stream_ptr(device=None):
+    """torch's current HIP stream ON `device` (a torch.device or an index; default: the current device) as an integer
+    handle."""
+    if device is None:
+        index = _cur_device()
+    else:
+        index = device if isinstance(device, int) else device.index
+        if index is None:
+            index = _cur_device()
+    return _raw_stream(index)
+
+
+class on_device:
+    """`with on_device(t.device):` -- the library launches on the CURRENT device's stream and never calls hipSetDevice, and
+    callers of the reference never call torch.cuda.set_device (scripts/train.py:76,132 only build torch.device(f'cuda:{rank}')
+    and `.to(device)`).  Every entry point of this package that reaches the library therefore derives the device from its
+    tensors and makes it current for the duration of the call; nothing happens (one getter call) when it already is."""
+    __slots__ = ("index", "prev")
+
+    def __init__(self, device):
+        self.index = device if isinstance(device, int) else device.index
+        self.prev = -1
+
+    def __enter__(self):
+        if self.index is not None and _cur_device() != self.index:
+            self.prev = _exchange_device(self.index)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            _exchange_device(self.prev)
+            self.prev = -1
+        return False
 
 
 def check(status, where):

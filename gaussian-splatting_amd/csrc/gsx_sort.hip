@@ -384,7 +384,10 @@ GSX_API int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_i
                                int check_bit, uint64_t* mismatch_dev, void* ws, size_t ws_bytes, void* stream)
 {
     if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit || check_bit < 0 || check_bit > 32) return GSX_E_INVALID;
-    if (n == 0) return GSX_OK;
+    if (n == 0) {       // nothing to sort, but the caller reads the mismatch count either way: no key differs
+        if (mismatch_dev) GSX_HIP(hipMemsetAsync(mismatch_dev, 0, 8, (hipStream_t)stream));
+        return GSX_OK;
+    }
     if (!keys_in || !keys_out || !values_out || !keys_tmp || !values_tmp || !ws) return GSX_E_INVALID;
     if (keys_in == keys_out || keys_in == keys_tmp || keys_out == keys_tmp) return GSX_E_INVALID;
     return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, nullptr, begin_bit, end_bit,

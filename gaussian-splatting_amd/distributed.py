@@ -6,12 +6,24 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm; "gloo" o
 tests).  The path shards over camera views; parameters are replicated; the only exchange step is
 the gradient average after the local backward.  There is nothing to overlap it with: every
 Gaussian's gradient is final only when the last tile of the last local view has finished.
+
+Two wrappers, same behaviour, for the two sides of the reference trainer's `isinstance(model,
+DistributedDataParallel)` switch (training/trainer.py:49-61, 80-81, 91, 228-235, 251-253, 286-289):
+  DataParallelSplat        isinstance is False: the trainer's plain-model branches run, so the wrapper forwards the
+                           model's attributes (`model.positions` ...) and speaks the model's own prefix-free
+                           state_dict; metrics are NOT reduced by the trainer on that branch (`reduce_metrics` is there).
+  ddp_compatible(...)      the same wrapper as a DistributedDataParallel subclass (DDP's constructor never runs: no
+                           reducer, no buckets): isinstance is True, every DDP branch of the trainer -- `model.module.*`,
+                           `_sync_model_params`, `_reduce_tensor`, checkpoint unwrap -- runs unedited.
 """
+import contextlib
 import os
 import torch
 import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel
 
 PARAM_ORDER = ("rotations", "positions", "scales", "opacity", "features")   # layout of the flat buffers
+FLAG_WORDS = 8             # per-tensor presence flags ride behind the gradients (render.GRAD_TAIL spare floats)
 
 
 def shard_views(n_views, rank, world):
@@ -19,9 +31,10 @@ def shard_views(n_views, rank, world):
     return list(range(rank, n_views, world))
 
 
-def _flat_view_of(tensors):
+def _flat_view_of(tensors, tail=0):
     """If the tensors are consecutive views into one contiguous storage (as RenderFunction.backward
-    lays the gradients out), return that flat tensor without copying; else None."""
+    lays the gradients out) with at least `tail` more elements behind the last, return that flat tensor
+    (tail included) without copying; else None."""
     t0 = tensors[0]
     base = t0.untyped_storage().data_ptr()
     expect = t0.data_ptr()
@@ -32,20 +45,28 @@ def _flat_view_of(tensors):
         expect += t.numel() * t.element_size(); total += t.numel()
     off = (t0.data_ptr() - base) // t0.element_size()
     flat_all = torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage())
-    return flat_all[off:off + total]
+    if off + total + tail > flat_all.numel():
+        return None
+    return flat_all[off:off + total + tail]
 
 
 class DataParallelSplat(torch.nn.Module):
-    """Wraps a GaussianSplat the way the reference wraps it in DDP (`.module` holds the model so
-    trainer code written against DDP keeps working), broadcasts rank 0's parameters once
-    (trainer.py:83-87) and averages gradients with one all-reduce (DDP semantics: SUM / world).
+    """Wraps a GaussianSplat the way the reference wraps it in DDP (`.module` holds the model), broadcasts rank 0's
+    parameters once (trainer.py:83-87) and averages gradients with one collective (DDP semantics: SUM / world).
 
-    auto_sync=True fires the all-reduce from autograd hooks as soon as all five parameter
-    gradients of a backward are final -- like DDP, the caller only calls loss.backward().
+    auto_sync=True fires the exchange from autograd, ONCE per backward, after the last gradient of that backward has
+    been accumulated -- like DDP, the caller only calls loss.backward().  What is exchanged is fixed by the model, not by
+    the backward: the gradients of every parameter with requires_grad, in PARAM_ORDER, plus one presence flag per
+    tensor.  A parameter the local backward did not reach contributes zeros; one that NO rank reached keeps grad None
+    (what DDP(find_unused_parameters=True) does, scripts/train.py:135-139), so a frozen tensor or a regulariser-only loss
+    neither skips the exchange nor leaves the ranks waiting for each other.
     """
 
     def __init__(self, module, process_group=None, auto_sync=True, broadcast=True, force_collectives=False, schedule=None):
         super().__init__()
+        self._setup(module, process_group, auto_sync, broadcast, force_collectives, schedule)
+
+    def _setup(self, module, process_group, auto_sync, broadcast, force_collectives, schedule):
         self.module = module
         # "allreduce": one RCCL all-reduce (default).  "mesh": the direct schedule of SURVEY 8e -- every rank sends slice j of
         # its gradients straight to rank j (all-to-all: all seven xGMI links of a GPU carry S/8 at once), sums the eight
@@ -57,60 +78,193 @@ class DataParallelSplat(torch.nn.Module):
         if self.schedule not in ("allreduce", "mesh", "auto"):
             raise ValueError(f"unknown data-parallel schedule {self.schedule!r}")
         self.tuned_ms = None
+        self.tune_error = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())   # world 1: rehearsal only
-        self._params = [getattr(module, k) for k in PARAM_ORDER]
-        self._pending = 0
+        self._names = [k for k in PARAM_ORDER if hasattr(module, k)]
+        self._sync_enabled = True
+        self._callback_queued = False
+        self._mesh_scratch = {}
+        self._flag_cache = {}
         self.last_allreduce_bytes = 0
         self.last_sync_was_flat = None
+        self.time_exchange = False              # True: HIP events around every exchange, collected in exchange_events
+        self.exchange_events = []
         if broadcast and self.active:
             self.broadcast_parameters()
         if auto_sync and self.active:
-            for p in self._params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+            for k in self._names:               # a tensor frozen at wrap time has no hook (and is not exchanged)
+                if getattr(module, k).requires_grad:
+                    getattr(module, k).register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- the plain-model face of the wrapper (the reference trainer's non-DDP branches) ---------------------------
+    def __getattr__(self, name):
+        """`model.positions`, `.num_gaussians`, `.chunk_size`, maintenance methods ...: whatever the wrapper does not
+        have itself is the wrapped model's (trainer.py:56-60 builds the optimizer from `model.<parameter>`)."""
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            modules = self.__dict__.get("_modules") or {}
+            if name != "module" and "module" in modules:
+                return getattr(modules["module"], name)
+            raise
+
+    def state_dict(self, *args, **kwargs):
+        """The wrapped model's own keys (`positions`, ... -- no `module.` prefix): trainer.py:253 saves
+        `self.model.state_dict()` on this branch, and the checkpoint must load into a plain GaussianSplat."""
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """Accepts the model's own keys and -- for checkpoints a DDP-wrapped run wrote with `model.state_dict()` --
+        `module.`-prefixed ones."""
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+        return self.module.load_state_dict(state_dict, *args, **kwargs)
 
     def forward(self, camera_poses, image_size):
+        self._callback_queued = False           # a backward that raised never ran its callback
         return self.module(camera_poses, image_size)
 
+    def exchange_ms(self, clear=True):
+        """mean duration of the timed exchanges (time_exchange = True) in ms, from their HIP events; synchronises"""
+        if not self.exchange_events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.exchange_events) / len(self.exchange_events)
+        if clear:
+            self.exchange_events = []
+        return ms
+
+    def _dp_params(self):
+        """the parameters in the exchange: requires_grad, in PARAM_ORDER -- the same set on every rank by construction
+        (replicated model), whatever a particular backward touched"""
+        return [getattr(self.module, k) for k in self._names if getattr(self.module, k).requires_grad]
+
     def broadcast_parameters(self, src=0):
-        flat = torch.cat([p.data.reshape(-1) for p in self._params])
+        params = [getattr(self.module, k) for k in self._names]
+        flat = torch.cat([p.data.reshape(-1) for p in params])
         dist.broadcast(flat, src, group=self.group)
         off = 0
-        for p in self._params:
+        for p in params:
             p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation over several backwards without an exchange (DistributedDataParallel.no_sync)."""
+        old = self._sync_enabled
+        self._sync_enabled = False
+        try:
+            yield
+        finally:
+            self._sync_enabled = old
+
     def _on_grad(self, _p):
-        self._pending += 1
-        if self._pending == len(self._params):
-            self._pending = 0
-            self.sync_gradients()
+        # Counting hook firings (five = done) breaks as soon as a backward reaches fewer tensors, and the stale count then
+        # fires the collective in the middle of the next backward.  The first gradient of a backward queues ONE callback
+        # that the autograd engine runs when that backward has finished.
+        if self._callback_queued or not self._sync_enabled:
+            return
+        self._callback_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._after_backward)
+
+    def _after_backward(self):
+        self._callback_queued = False
+        self.sync_gradients()
 
     def sync_gradients(self):
-        """Average .grad of the five parameters over all ranks in one collective."""
+        """Average .grad of the exchanged parameters over all ranks in one collective."""
         if not self.active:
             return
-        grads = [p.grad for p in self._params]
-        if any(g is None for g in grads):
-            raise RuntimeError("sync_gradients: a parameter has no gradient")
-        flat = _flat_view_of(grads)
+        params = self._dp_params()
+        if not params:
+            return
+        grads = [p.grad for p in params]
+        k = len(params)
+        dev = params[0].device
+        flat = None
+        if all(g is not None for g in grads):
+            flat = _flat_view_of(grads, FLAG_WORDS)          # the render backward's own buffer: no copy
         packed = flat is None
         self.last_sync_was_flat = not packed
+        total = sum(p.numel() for p in params)
         if packed:
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            # a second autograd route into a parameter (the opacity regulariser, trainer.py:56-67 of this package) makes
+            # AccumulateGrad own a fresh tensor; a frozen or unreached tensor leaves a hole: gather into one buffer
+            flat = torch.empty(total + FLAG_WORDS, dtype=params[0].dtype, device=dev)
+            off = 0
+            for p, g in zip(params, grads):
+                dst = flat[off:off + p.numel()]
+                if g is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(g.reshape(-1))
+                off += p.numel()
+        flags = flat[total:total + FLAG_WORDS]
+        pattern = tuple(1.0 if (i < k and grads[i] is not None) else 0.0 for i in range(FLAG_WORDS))
+        src = self._flag_cache.get((pattern, dev))
+        if src is None:                                      # one host-to-device copy per pattern, not per step
+            src = self._flag_cache[(pattern, dev)] = torch.tensor(pattern, dtype=flat.dtype).to(dev)
+        flags.copy_(src)
         if self.schedule == "auto":
-            self.tune_schedule(flat.numel(), flat.device)
+            self.tune_schedule(flat.numel(), dev)
+        ev = None
+        if self.time_exchange and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self._average(flat, self.schedule)
+        if ev is not None:
+            ev[1].record()
+            self.exchange_events.append(ev)
         self.last_allreduce_bytes = flat.numel() * flat.element_size()
         if packed:
+            # the averaged gradients stay where they are: .grad becomes a view of the exchange buffer (no copy back), and
+            # the five are consecutive again for whoever walks them next (clip_grad_norm_, the fused optimizer)
+            seen = flags.tolist() if any(g is None for g in grads) else None
             off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+            for i, p in enumerate(params):
+                if seen is None or seen[i] != 0.0:           # reached on some rank
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()                             # reached on no rank: grad stays None, like DDP
+
+    def reduce_metrics(self, metrics, device=None):
+        """trainer.py:228-233 for the plain-model branch: scalar entries averaged over the ranks, the rest passed through."""
+        return {k: reduce_metric(v, device, self.group) if isinstance(v, (float, int)) else v for k, v in metrics.items()}
+
+
+class _DDPFace(DataParallelSplat, DistributedDataParallel):
+    """DataParallelSplat that also answers `isinstance(model, DistributedDataParallel)`.  DistributedDataParallel's
+    constructor is never run -- there is no reducer and there are no buckets; every method that matters is
+    DataParallelSplat's (MRO) -- so the only thing inherited is the type, which is what the reference trainer tests.
+    state_dict()/load_state_dict() keep DDP's `module.`-prefixed form here, as a DDP-wrapped model's would."""
+
+    def __init__(self, module, **kwargs):
+        torch.nn.Module.__init__(self)
+        self._setup(module, kwargs.pop("process_group", None), kwargs.pop("auto_sync", True), kwargs.pop("broadcast", True),
+                    kwargs.pop("force_collectives", False), kwargs.pop("schedule", None))
+        if kwargs:
+            raise TypeError(f"unexpected arguments {sorted(kwargs)}")
+        # attributes DistributedDataParallel's inherited helpers look at
+        self.require_backward_grad_sync = True
+        self.device_ids = None
+        self.process_group = self.group
+
+    state_dict = torch.nn.Module.state_dict
+    load_state_dict = torch.nn.Module.load_state_dict
+
+    def __getstate__(self):
+        raise TypeError("a data-parallel wrapper is per process: pickle .module instead")
+
+
+def ddp_compatible(module, **kwargs):
+    """DataParallelSplat for callers that switch on isinstance(model, DistributedDataParallel) -- the reference's trainer
+    (training/trainer.py:49-61,80-81,91,228,251-253,286-289) then takes its DDP branches unedited."""
+    return _DDPFace(module, **kwargs)
 
 
 def _average_impl(self, flat, schedule):
     if schedule == "mesh":
-        _mesh_average_impl(flat, self.world, self.group)
+        _mesh_average_impl(flat, self.world, self.group, self._mesh_scratch)
     elif flat.is_cuda and dist.get_backend(self.group) == "nccl":
         # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
@@ -119,55 +273,81 @@ def _average_impl(self, flat, schedule):
         flat.mul_(1.0 / self.world)
 
 
+def _mesh_supported(group, device):
+    """LOCAL answer to "can this rank run the mesh schedule" (all_to_all_single + all_gather_into_tensor on `device`),
+    given without entering a collective: a rank that found out by trying would leave its peers inside the all-to-all."""
+    try:
+        backend = dist.get_backend(group)
+    except Exception:
+        return False
+    if device is not None and torch.device(device).type == "cuda":
+        return backend == "nccl" or backend.endswith("nccl")
+    return backend in ("gloo", "mpi") or "gloo" in backend
+
+
 def _tune_schedule_impl(self, numel, device, reps=3):
     """Times both exchange schedules on a scratch buffer of `numel` floats (one untimed call each, then `reps` timed ones
-    between barriers) and adopts the faster.  The two timings are MAX-reduced over the ranks before they are compared, so
-    every rank takes the same decision -- ranks on different schedules would deadlock in the next exchange."""
+    between barriers) and adopts the faster.  Every decision is collective.  Whether the mesh schedule may be tried at all
+    is each rank's LOCAL capability answer MIN-reduced over the ranks, before anybody enters it (a rank-local failure
+    inside a trial -- out of memory, a communicator error -- is not caught: its peers are inside the collective by then,
+    so the only honest outcome is the job's failure); the timings are MAX-reduced before they are compared.  Ranks on
+    different schedules, or in different collectives, would deadlock."""
     import time
     buf = torch.zeros(numel, dtype=torch.float32, device=device)
     sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
+    ok = 1.0 if _mesh_supported(self.group, device) else 0.0
+    flag = torch.tensor([ok], dtype=torch.float32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # every rank reaches this, whatever it answered
+    if ok == 0.0:
+        self.tune_error = "mesh schedule not supported by this rank's backend"
+    candidates = ("allreduce", "mesh") if float(flag.item()) > 0.0 else ("allreduce",)
     times = []
-    for sched in ("allreduce", "mesh"):
-        try:
+    for sched in candidates:
+        self._average(buf, sched)
+        sync(); dist.barrier(group=self.group); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
             self._average(buf, sched)
-            sync(); dist.barrier(group=self.group); sync()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                self._average(buf, sched)
-            sync()
-            times.append((time.perf_counter() - t0) / reps)
-        except RuntimeError as e:          # a backend without all_to_all_single refuses on every rank alike: keep the all-reduce
-            if sched == "allreduce":
-                raise
-            self.tune_error = str(e).splitlines()[0][:200]
-            times.append(float("inf"))
+        sync()
+        times.append((time.perf_counter() - t0) / reps)
+    times += [float("inf")] * (2 - len(times))
     t = torch.tensor(times, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
     t = [float(x) for x in t.cpu()]
     self.tuned_ms = {"allreduce": round(t[0] * 1e3, 4), "mesh": round(t[1] * 1e3, 4) if t[1] != float("inf") else None}
     self.schedule = "allreduce" if t[0] <= t[1] else "mesh"
+    self._mesh_scratch.clear()
     return self.schedule
 
 
-def _mesh_average_impl(flat, world, group):
+def _mesh_average_impl(flat, world, group, scratch=None):
     """flat <- mean over ranks, by all-to-all + local sum + all-gather.  Every rank reduces its own slice in rank order, so
-    all ranks end up with the same bits (the replicas must not drift apart)."""
+    all ranks end up with the same bits (the replicas must not drift apart).  `scratch` (a dict the caller keeps) holds
+    the receive / padding buffers from one exchange to the next: the sizes repeat every step."""
     n = flat.numel()
     chunk = (n + world - 1) // world
     padded = chunk * world != n
+    key = (n, world, flat.dtype, flat.device)
+    bufs = scratch.get(key) if scratch is not None else None
+    if bufs is None:
+        bufs = (torch.empty(chunk * world, dtype=flat.dtype, device=flat.device),
+                torch.zeros(chunk * world, dtype=flat.dtype, device=flat.device) if padded else None,
+                torch.empty(chunk, dtype=flat.dtype, device=flat.device))
+        if scratch is not None:
+            scratch.clear(); scratch[key] = bufs
+    recv, pad, mine = bufs
     send = flat
     if padded:
-        send = flat.new_zeros(chunk * world); send[:n] = flat
-    recv = torch.empty_like(send)
+        send = pad; send[:n] = flat
     dist.all_to_all_single(recv, send, group=group)            # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY slice
-    mine = recv.view(world, chunk).sum(0)
+    torch.sum(recv.view(world, chunk), 0, out=mine)
     mine.mul_(1.0 / world)
     dist.all_gather_into_tensor(send, mine, group=group)
     if padded:
         flat.copy_(send[:n])
 
 
-DataParallelSplat._mesh_average = lambda self, flat: _mesh_average_impl(flat, self.world, self.group)
+DataParallelSplat._mesh_average = lambda self, flat: _mesh_average_impl(flat, self.world, self.group, self._mesh_scratch)
 DataParallelSplat._average = _average_impl
 DataParallelSplat.tune_schedule = _tune_schedule_impl
 

@@ -42,14 +42,17 @@ class _ImageLoss(torch.autograd.Function):
         wsb = lib.gsx_image_loss_workspace_bytes()
         ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
         ctx.kind = kind
+        st = _stream(p.device)                      # the stream of the prediction's device, not of the current one
         if ctx.needs_input_grad[0]:
             # the loss is almost always the root of the backward: write dLoss/dpred for upstream 1 in the same pass
             d = torch.empty_like(p)
-            L.check(lib.gsx_image_loss_fwd_grad(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(d), _ptr(ws), wsb, _stream()),
-                    "gsx_image_loss_fwd_grad")
+            with L.on_device(p.device):
+                L.check(lib.gsx_image_loss_fwd_grad(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(d), _ptr(ws), wsb, st),
+                        "gsx_image_loss_fwd_grad")
             ctx.save_for_backward(p, t, d)
         else:
-            L.check(lib.gsx_image_loss_fwd(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(ws), wsb, _stream()), "gsx_image_loss_fwd")
+            with L.on_device(p.device):
+                L.check(lib.gsx_image_loss_fwd(kind, _ptr(p), _ptr(t), p.numel(), _ptr(loss), _ptr(ws), wsb, st), "gsx_image_loss_fwd")
             ctx.save_for_backward(p, t)
         return loss
 
@@ -64,7 +67,8 @@ class _ImageLoss(torch.autograd.Function):
         lib = L.lib()
         d = torch.empty_like(p)
         g = g.detach().contiguous().float()
-        L.check(lib.gsx_image_loss_bwd(ctx.kind, _ptr(p), _ptr(t), p.numel(), _ptr(g), _ptr(d), _stream()), "gsx_image_loss_bwd")
+        with L.on_device(p.device):
+            L.check(lib.gsx_image_loss_bwd(ctx.kind, _ptr(p), _ptr(t), p.numel(), _ptr(g), _ptr(d), _stream(p.device)), "gsx_image_loss_bwd")
         return d, None, None
 
 
@@ -93,7 +97,8 @@ class _L1Ssim(torch.autograd.Function):
         loss3 = torch.empty(3, dtype=torch.float32, device=p.device)
         wsb = lib.gsx_l1_ssim_workspace_bytes(planes, H, W)
         ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
-        L.check(lib.gsx_l1_ssim_fwd(_ptr(p), _ptr(t), planes, H, W, float(lambda_dssim), _ptr(loss3), _ptr(ws), wsb, _stream()), "gsx_l1_ssim_fwd")
+        with L.on_device(p.device):
+            L.check(lib.gsx_l1_ssim_fwd(_ptr(p), _ptr(t), planes, H, W, float(lambda_dssim), _ptr(loss3), _ptr(ws), wsb, _stream(p.device)), "gsx_l1_ssim_fwd")
         ctx.lam = float(lambda_dssim)
         ctx.save_for_backward(p, t, ws)
         ctx.mark_non_differentiable(loss3)
@@ -107,7 +112,8 @@ class _L1Ssim(torch.autograd.Function):
         planes = p.numel() // (H * W)
         d = torch.empty_like(p)
         g = g.detach().contiguous().float()
-        L.check(lib.gsx_l1_ssim_bwd(_ptr(p), _ptr(t), planes, H, W, ctx.lam, _ptr(g), _ptr(ws), ws.numel(), _ptr(d), _stream()), "gsx_l1_ssim_bwd")
+        with L.on_device(p.device):
+            L.check(lib.gsx_l1_ssim_bwd(_ptr(p), _ptr(t), planes, H, W, ctx.lam, _ptr(g), _ptr(ws), ws.numel(), _ptr(d), _stream(p.device)), "gsx_l1_ssim_bwd")
         return d, None, None
 
 

@@ -105,23 +105,24 @@ class GaussianSplat(nn.Module):
         from . import _lib as L
         lib = L.lib()
         n = self.opacity.shape[0]; dev = self.opacity.device
-        st = L.stream_ptr()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         total = torch.zeros(1, dtype=torch.int64, device=dev)
         wsb = lib.gsx_scan_workspace_bytes(max(n, 1)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        L.check(lib.gsx_keep_flags(ptr(self.opacity.data.contiguous()), n, float(threshold), ptr(keep), st), "gsx_keep_flags")
-        L.check(lib.gsx_scan_u32(ptr(keep), ptr(offsets), ptr(total), n, ptr(ws), wsb, st), "gsx_scan_u32")
-        kept = int(total.item())
         out = []
-        for p in params:
-            src = p.data.contiguous().float()
-            row = src.numel() // max(n, 1)
-            dst = torch.empty((kept,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
-            if kept:
-                L.check(lib.gsx_compact_rows(ptr(src), ptr(keep), ptr(offsets), n, row, ptr(dst), st), "gsx_compact_rows")
-            out.append(dst)
+        with L.on_device(dev):                       # launches follow the parameters' device, not the current one
+            st = L.stream_ptr(dev)
+            L.check(lib.gsx_keep_flags(ptr(self.opacity.data.contiguous()), n, float(threshold), ptr(keep), st), "gsx_keep_flags")
+            L.check(lib.gsx_scan_u32(ptr(keep), ptr(offsets), ptr(total), n, ptr(ws), wsb, st), "gsx_scan_u32")
+            kept = int(total.item())
+            for p in params:
+                src = p.data.contiguous().float()
+                row = src.numel() // max(n, 1)
+                dst = torch.empty((kept,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+                if kept:
+                    L.check(lib.gsx_compact_rows(ptr(src), ptr(keep), ptr(offsets), n, row, ptr(dst), st), "gsx_compact_rows")
+                out.append(dst)
         self._replace_parameters(out)
 
     def add_gaussians(self, num_new: int) -> None:
@@ -150,8 +151,10 @@ class GaussianSplat(nn.Module):
         s = self.scales.data
         if not s.is_contiguous():
             s = s.contiguous(); self.scales.data = s
-        L.check(L.lib().gsx_clamp_inplace(C.c_void_p(s.data_ptr()), s.numel(), 0.0001, 1.0,
-                                          L.stream_ptr()), "gsx_clamp_inplace")
+        with L.on_device(s.device):
+            L.check(L.lib().gsx_clamp_inplace(C.c_void_p(s.data_ptr()), s.numel(), 0.0001, 1.0,
+                                              L.stream_ptr(s.device)), "gsx_clamp_inplace")
+        torch.autograd.graph.increment_version(self.scales)      # written through a raw pointer: autograd must see it
 
     @torch.no_grad()
     def get_dense_points(self, num_points: int = 1000000) -> torch.Tensor:

@@ -29,7 +29,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         # The step count lives in a Python int per parameter; the `step` tensors torch.optim.Adam keeps in its state are
         # refreshed only when the state is read (state_dict): five CPU tensor increments + .item() calls per step were a
         # third of this method's host time, which is what bounds a small scene's trainer step.
-        ps, gs, ms, vs, ns, lrs = [], [], [], [], [], []
+        ps, gs, ms, vs, ns, lrs, touched = [], [], [], [], [], [], []
         step = None
         for group in self.param_groups:
             lr = float(group['lr'])
@@ -53,6 +53,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                     step = s
                 elif step != s:
                     raise RuntimeError("FusedClipAdam: parameters are at different step counts")
+                touched.append(p)
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st['exp_avg'].data_ptr())
                 vs.append(st['exp_avg_sq'].data_ptr()); ns.append(p.numel()); lrs.append(lr)
         if not ps:
@@ -61,15 +62,20 @@ class FusedClipAdam(torch.optim.Optimizer):
         if k > 8:
             raise RuntimeError("FusedClipAdam handles at most 8 tensors per step")
         lib = L.lib()
-        dev = self.param_groups[0]['params'][0].device
+        dev = touched[0].device
+        if any(p.device != dev for p in touched):
+            raise RuntimeError("FusedClipAdam: all parameters must live on one device")
         if self._ws is None or self._ws.device != dev:
             self._ws = torch.empty(lib.gsx_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
         arr = lambda v: (C.c_void_p * k)(*v)
         b1, b2 = self.param_groups[0]['betas']
-        L.check(lib.gsx_clip_adam_step(k, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * k)(*ns), (C.c_float * k)(*lrs),
-                                       b1, b2, self.param_groups[0]['eps'], step, self.max_grad_norm,
-                                       1 if self.write_clipped_grad else 0, self._ws.data_ptr(), self._ws.numel(),
-                                       L.stream_ptr()), "gsx_clip_adam_step")
+        with L.on_device(dev):
+            L.check(lib.gsx_clip_adam_step(k, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * k)(*ns), (C.c_float * k)(*lrs),
+                                           b1, b2, self.param_groups[0]['eps'], step, self.max_grad_norm,
+                                           1 if self.write_clipped_grad else 0, self._ws.data_ptr(), self._ws.numel(),
+                                           L.stream_ptr(dev)), "gsx_clip_adam_step")
+        # the kernel wrote the parameters through raw pointers: tell autograd (a backward that saved them must refuse to run)
+        torch.autograd.graph.increment_version(touched)
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

@@ -309,9 +309,10 @@ def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True)
     # the sort itself counts the keys that break the assumption, the count travels with D, and a view sorted on too few
     # bits is redone on all 32.
     n = params[0].shape[0]
-    att = _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd)
-    while not _check_view(att):
+    with L.on_device(params[0].device):
         att = _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd)
+        while not _check_view(att):
+            att = _enqueue_any(params, pose, n, H, W, order, want_depth, need_bwd)
     return _finish_view(att, pose, att.mean2d, att.depth, att.cov2d)
 
 
@@ -471,6 +472,9 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
                                    n, 1 if accumulate else 0, *[_ptr(g) for g in grads], _stream()), "gsx_preprocess_bwd")
 
 
+GRAD_TAIL = 8
+
+
 class RenderFunction(torch.autograd.Function):
     """(positions, scales, rotations, opacity, features, poses (B,4,4)) ->
        rendered_images (B,3,H,W), positions2d (B,N,2), depths (B,N), cov2d (B,N,2,2),
@@ -491,12 +495,19 @@ class RenderFunction(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad[:5])
         outs, views = [], []
         order = None
-        for b in range(B):
-            o, vs, _ = forward_view(params, poses[b], H, W, order=order, want_depth=want_depth, need_bwd=need_bwd)
-            if order is None and B > 1:
-                order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
-            outs.append(o); views.append(vs)
-        ctx.params, ctx.views, ctx.hw = params, views, (H, W)
+        # the kernels go to the stream of the PARAMETERS' device, whatever the caller's current device is (the reference's
+        # launcher never calls set_device: scripts/train.py:76,132)
+        with L.on_device(dev):
+            for b in range(B):
+                o, vs, _ = forward_view(params, poses[b], H, W, order=order, want_depth=want_depth, need_bwd=need_bwd)
+                if order is None and B > 1:
+                    order = vs.order       # every view is composited in view 0's order (gaussian_splatting.py:206)
+                outs.append(o); views.append(vs)
+        # detach() shares the version counter: an in-place update of a parameter between forward and backward (the backward
+        # recomputes the projection from the live parameter memory) raises autograd's version error instead of mixing old
+        # records with new projections
+        ctx.save_for_backward(*params)
+        ctx.views, ctx.hw = views, (H, W)
         # B == 1 (the reference's only working batch size): views, no copies
         cat = (lambda i: outs[0][i].unsqueeze(0)) if B == 1 else (lambda i: torch.stack([o[i] for o in outs]))
         rgb, alpha, dmap, mean2d, depth, cov2d = (cat(i) if outs[0][i] is not None else rgb_placeholder(outs[0][0])
@@ -507,21 +518,24 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_rgb, d_mean2d, d_depth, d_cov2d, _a, _d, _s):
-        params = ctx.params
+        params = ctx.saved_tensors
         n = params[0].shape[0]
         # one flat 14*N gradient buffer (rotations first: its float4 stores need 16-byte alignment);
         # the data-parallel path all-reduces this buffer in ONE collective (distributed.py)
-        flat = torch.empty(14 * n, dtype=torch.float32, device=params[0].device)
+        # GRAD_TAIL spare floats behind the gradients: the data-parallel wrapper parks its per-tensor presence flags there,
+        # so that gradients + flags are one contiguous run and still ONE collective without a copy
+        flat = torch.empty(14 * n + GRAD_TAIL, dtype=torch.float32, device=params[0].device)
         g_rot = flat[0:4 * n].view(n, 4); g_pos = flat[4 * n:7 * n].view(n, 3); g_scl = flat[7 * n:10 * n].view(n, 3)
         g_opa = flat[10 * n:11 * n].view(n, 1); g_fea = flat[11 * n:14 * n].view(n, 3)
         grads = [g_pos, g_scl, g_rot, g_opa, g_fea]
-        for b, vs in enumerate(ctx.views):
-            backward_view(params, vs,
-                          None if d_rgb is None else _f32c(d_rgb[b]),
-                          None if d_mean2d is None else _f32c(d_mean2d[b]),
-                          None if d_depth is None else _f32c(d_depth[b]),
-                          None if d_cov2d is None else _f32c(d_cov2d[b]),
-                          grads, accumulate=(b > 0))
+        with L.on_device(params[0].device):
+            for b, vs in enumerate(ctx.views):
+                backward_view(params, vs,
+                              None if d_rgb is None else _f32c(d_rgb[b]),
+                              None if d_mean2d is None else _f32c(d_mean2d[b]),
+                              None if d_depth is None else _f32c(d_depth[b]),
+                              None if d_cov2d is None else _f32c(d_cov2d[b]),
+                              grads, accumulate=(b > 0))
         return grads[0], grads[1], grads[2], grads[3], grads[4], None, None, None, None
 
 
@@ -549,6 +563,11 @@ def render_orbit(positions, scales, rotations, opacity, features, poses, image_s
     if not positions.is_cuda:
         raise RuntimeError("gaussian-splatting_amd renders on an MI355X only: parameters must live on a CUDA(HIP) device; "
                            "there is no CPU fallback")
+    with L.on_device(positions.device):               # streams, events and launches all belong to the parameters' device
+        return _render_orbit(positions, scales, rotations, opacity, features, poses, image_size, out, streams)
+
+
+def _render_orbit(positions, scales, rotations, opacity, features, poses, image_size, out, streams):
     H, W = int(image_size[0]), int(image_size[1])
     params = tuple(_f32c(t.detach()) for t in (positions, scales, rotations, opacity, features))
     poses = _f32c(poses.detach().to(positions.device))

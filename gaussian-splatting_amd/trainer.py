@@ -83,7 +83,12 @@ def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad
     outputs = model(camera_poses, target.shape[-2:])
     loss = loss_fn(outputs, target)
     loss.backward(gradient=_unit_gradient(loss))
-    if max_grad_norm > 0 and not hasattr(optimizer, "max_grad_norm"):      # the fused optimizer clips inside step()
+    fused = getattr(optimizer, "max_grad_norm", None)                     # FusedClipAdam clips inside step()
+    if fused is not None and fused > 0:
+        if float(fused) != float(max_grad_norm):
+            raise ValueError(f"train_step(max_grad_norm={max_grad_norm}) but the fused optimizer clips at {fused}: "
+                             "build it with the same value (make_optimizer(fused_clip_norm=...))")
+    elif max_grad_norm > 0:                                               # torch optimizer, or a fused one built without clipping
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
     return loss.detach()

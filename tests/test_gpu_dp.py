@@ -47,7 +47,7 @@ m = fresh()
 dp = DataParallelSplat(m)
 (dp(poses[rank:rank + 1], (H, W))["rendered_images"] * upstream[rank]).sum().backward()     # exchange fires from the hooks
 torch.cuda.synchronize()
-assert dp.last_sync_was_flat and dp.last_allreduce_bytes == 14 * N * 4
+assert dp.last_sync_was_flat and dp.last_allreduce_bytes == (14 * N + 8) * 4
 g0, g1 = local_grads(0), local_grads(1)
 for k in PARAM_ORDER:
     want = (g0[k] + g1[k]) * 0.5
@@ -68,7 +68,7 @@ for schedule in ("allreduce", "mesh", "auto"):
     dp = DataParallelSplat(m, force_collectives=True, schedule=schedule)
     (dp(poses[1:2], (H, W))["rendered_images"] * upstream[1]).sum().backward()
     torch.cuda.synchronize()
-    assert dp.last_sync_was_flat and dp.last_allreduce_bytes == 14 * N * 4, schedule
+    assert dp.last_sync_was_flat and dp.last_allreduce_bytes == (14 * N + 8) * 4, schedule
     if schedule == "auto":
         assert dp.schedule in ("allreduce", "mesh") and dp.tuned_ms is not None
     for k in PARAM_ORDER:

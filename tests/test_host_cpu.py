@@ -148,7 +148,7 @@ n = 50
 for mode in ("flat", "separate"):
     # emulate a local backward: gradients = rank-dependent values
     if mode == "flat":      # the layout RenderFunction.backward produces: views into one buffer
-        flat = torch.full((14 * n,), float(rank + 1))
+        flat = torch.full((14 * n + 8,), float(rank + 1))      # + the spare floats render.GRAD_TAIL leaves for the flags
         views = dict(rotations=flat[0:4*n].view(n, 4), positions=flat[4*n:7*n].view(n, 3), scales=flat[7*n:10*n].view(n, 3),
                      opacity=flat[10*n:11*n].view(n, 1), features=flat[11*n:14*n].view(n, 3))
         for k in PARAM_ORDER: getattr(m, k).grad = views[k]
@@ -159,7 +159,8 @@ for mode in ("flat", "separate"):
     for i, k in enumerate(PARAM_ORDER):
         exp = mean if mode == "flat" else mean * (i + 1)
         assert torch.allclose(getattr(m, k).grad, torch.full_like(getattr(m, k), exp)), (mode, k)
-    assert dp.last_allreduce_bytes == 14 * n * 4    # ONE collective over the whole 14*N buffer
+    assert dp.last_allreduce_bytes == (14 * n + 8) * 4    # ONE collective: the whole 14*N buffer + 8 presence flags
+    assert dp.last_sync_was_flat == (mode == "flat")
 # auto-sync from autograd hooks, like DDP: the caller only calls backward()
 for k in PARAM_ORDER: getattr(m, k).grad = None
 loss = sum((getattr(m, k) * float(rank + 1)).sum() for k in PARAM_ORDER)
