@@ -47,6 +47,7 @@ STAGE_KERNEL = {"composite_bwd": "chunk_bwd_kernel", "composite_fwd": "chunk_fwd
                 "project_fwd": "project_fwd_kernel"}
 N_VIEWS = 60
 VIEW_STRIDE = 7
+T_START = time.perf_counter()
 
 
 def pmc_traffic_bytes(stage):
@@ -182,12 +183,24 @@ def main():
     ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh", "auto"),
                     help="gradient exchange: one RCCL all-reduce (default), all-to-all + local sum + all-gather (SURVEY 8e's mesh "
                          "schedule), or auto = time both on a scratch buffer at the first exchange and keep the faster")
+    ap.add_argument("--verbose", action="store_true", help="phase progress lines on stderr")
+    ap.add_argument("--hang-dump", type=int, default=0, metavar="SECONDS",
+                    help="dump every thread's Python stack and exit if the run is still going after SECONDS")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    if args.hang_dump == 0 and args.gpus > 1:
+        args.hang_dump = 900                         # multi-rank default: a hang leaves a stack trace instead of silence
+    if args.hang_dump > 0:                           # a rank stuck in a collective prints where, then exits non-zero
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_dump, exit=True)
+
+    def phase(msg):
+        if args.verbose:
+            print(f"[bench rank {os.environ.get('RANK', '0')}] {msg} (+{time.perf_counter() - T_START:.1f} s)", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
@@ -228,8 +241,10 @@ def main():
     # (outside warm-up and timed region alike) and the faster is kept; the line reports the choice and both timings
     schedule = args.dp_schedule or os.environ.get("GSX_DP_SCHEDULE", "auto")
     net = DataParallelSplat(model, force_collectives=args.force_dp, schedule=schedule) if use_dp else model
+    phase("wrapper built")
     if use_dp and net.schedule == "auto":
         net.tune_schedule(14 * n + R.GRAD_TAIL, dev)
+        phase(f"schedule tuned: {net.schedule} {net.tuned_ms}")
     opt = make_optimizer(net, fused_clip_norm=None if args.torch_optimizer else 0.1)
     poses = torch.from_numpy(create_orbit_poses(4.0, N_VIEWS, 45.0)).to(dev)      # README.md:129-137
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -266,20 +281,23 @@ def main():
             for s in range(count):
                 step(first + s)
 
+    phase("model ready")
     run(0, args.warmup)
     fence()
+    phase("warm-up done")
     if use_dp:
         net.time_exchange = True                  # two HIP events per exchange, read after the timed region
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
+    phase("timed region done")
     exchange_ms = None
     if use_dp:
         net.time_exchange = False
         exchange_ms = net.exchange_ms()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -299,6 +317,7 @@ def main():
         loss_fn(out, target).backward()
     R.set_stage_timer(None)
     fence()
+    phase("per-kernel pass done")
     d_avg = d_sum / k_prof if k_prof else 0
     if rank == 0 and k_prof:
         tot = timer.totals_ms()

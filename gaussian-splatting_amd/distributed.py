@@ -87,6 +87,7 @@ class DataParallelSplat(torch.nn.Module):
         self._callback_queued = False
         self._mesh_scratch = {}
         self._flag_cache = {}
+        self._host_stage = None
         self.last_allreduce_bytes = 0
         self.last_sync_was_flat = None
         self.time_exchange = False              # True: HIP events around every exchange, collected in exchange_events
@@ -144,7 +145,12 @@ class DataParallelSplat(torch.nn.Module):
     def broadcast_parameters(self, src=0):
         params = [getattr(self.module, k) for k in self._names]
         flat = torch.cat([p.data.reshape(-1) for p in params])
-        dist.broadcast(flat, src, group=self.group)
+        if flat.is_cuda and dist.get_backend(self.group) != "nccl":       # gloo: through the host (see _average)
+            host = flat.cpu()
+            dist.broadcast(host, src, group=self.group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src, group=self.group)
         off = 0
         for p in params:
             p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
@@ -268,7 +274,19 @@ def _average_impl(self, flat, schedule):
     elif flat.is_cuda and dist.get_backend(self.group) == "nccl":
         # RCCL averages inside the collective: no separate 1/world pass over the 14*N buffer
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-    else:                                   # gloo (CPU tests) has no AVG
+    elif flat.is_cuda:
+        # gloo with device tensors (rehearsals of the N>1 path on one GPU, tests): staged through pinned host memory HERE.
+        # gloo's own device-tensor path hung intermittently on this image with both ranks inside the all-reduce of a
+        # 56 MB buffer (r2, two ranks sharing one MI355X); host tensors are the path gloo is built for.
+        host = self._host_stage
+        if host is None or host.numel() < flat.numel() or host.dtype != flat.dtype:
+            host = self._host_stage = torch.empty(flat.numel(), dtype=flat.dtype).pin_memory()
+        host = host[:flat.numel()]
+        host.copy_(flat)                    # synchronises with the producing stream
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        host.mul_(1.0 / self.world)
+        flat.copy_(host, non_blocking=True)
+    else:                                   # gloo on CPU tensors (the CPU tests) has no AVG
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world)
 
@@ -296,7 +314,8 @@ def _tune_schedule_impl(self, numel, device, reps=3):
     buf = torch.zeros(numel, dtype=torch.float32, device=device)
     sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
     ok = 1.0 if _mesh_supported(self.group, device) else 0.0
-    flag = torch.tensor([ok], dtype=torch.float32, device=device)
+    ctrl = device if dist.get_backend(self.group) == "nccl" else "cpu"     # control words: device tensors only for RCCL
+    flag = torch.tensor([ok], dtype=torch.float32, device=ctrl)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # every rank reaches this, whatever it answered
     if ok == 0.0:
         self.tune_error = "mesh schedule not supported by this rank's backend"
@@ -311,7 +330,7 @@ def _tune_schedule_impl(self, numel, device, reps=3):
         sync()
         times.append((time.perf_counter() - t0) / reps)
     times += [float("inf")] * (2 - len(times))
-    t = torch.tensor(times, dtype=torch.float64, device=device)
+    t = torch.tensor(times, dtype=torch.float64, device=ctrl)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
     t = [float(x) for x in t.cpu()]
     self.tuned_ms = {"allreduce": round(t[0] * 1e3, 4), "mesh": round(t[1] * 1e3, 4) if t[1] != float("inf") else None}
@@ -356,6 +375,6 @@ def reduce_metric(value, device=None, group=None):
     """Scalar metric averaged over ranks (trainer.py:89-97)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()) / dist.get_world_size(group)
