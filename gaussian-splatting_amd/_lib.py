@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgsplat_gfx950.so")
 # every symbol include/gsx.h declares
 SYMBOLS = [
     "gsx_strerror", "gsx_last_hip_error", "gsx_abi_version",
-    "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32",
+    "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32", "gsx_sort_pairs_u32_static",
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
     "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks",
     "gsx_view_layout", "gsx_view_forward",
@@ -22,7 +22,7 @@ SYMBOLS = [
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
-ABI_VERSION = 12            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 13            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -30,6 +30,7 @@ TILE = 16
 CHUNK = 256
 STATE_WORDS = 8
 DEPTH_CHECK_BIT = 24        # GSX_DEPTH_CHECK_BIT
+STATIC_SORT_MAX_N = 1 << 20 # GSX_STATIC_SORT_MAX_N
 # GSX_VIEW_* slots of gsx_constants.h (buffers of one view inside the arena of gsx_view_forward)
 VIEW_SLOT_NAMES = ("order", "rank_of", "rec", "tt", "offsets", "tiles", "ranks", "ranges", "chunk_base", "chunk_state",
                    "total", "partials", "depth_keys", "pre", "keys_out", "keys_tmp", "values_tmp", "sort_ws", "tt_block_sums", "tile_box",
@@ -67,6 +68,7 @@ def lib():
     L.gsx_project_fwd.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]
     L.gsx_sort_workspace_bytes.restype = _sz; L.gsx_sort_workspace_bytes.argtypes = [_i64]
     L.gsx_sort_pairs_u32.argtypes = [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _sz, _p]
+    L.gsx_sort_pairs_u32_static.argtypes = [_p, _p, _p, _p, _i64, C.c_int, C.c_int, _p]
     L.gsx_scan_workspace_bytes.restype = _sz; L.gsx_scan_workspace_bytes.argtypes = [_i64]
     L.gsx_scan_u32.argtypes = [_p, _p, _p, _i64, _p, _sz, _p]
     L.gsx_build_records.argtypes = [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]

@@ -6,6 +6,7 @@
 //     instances are emitted in rank order, so a STABLE sort on the tile id alone yields the
 //     (tile << 32 | rank) key order with 4-byte keys and 2 passes instead of 64-bit keys and 5.
 // HBM-bound integer work: coalesced 4-byte streams, digit ranking with wave64 ballots, no MFMA.
+#include <atomic>
 #include "gsx_common.h"
 
 namespace gsx {
@@ -402,4 +403,60 @@ GSX_API int gsx_scan_u32(const uint32_t* in, uint32_t* out_exclusive, uint64_t* 
     if (n < 0) return GSX_E_INVALID;
     if (n > 0 && (!in || !out_exclusive || !ws)) return GSX_E_INVALID;
     return scan_internal(in, out_exclusive, total_dev, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing and takes no workspace (no counterpart in the reference): the same sort,
+// same kernels, with the ping-pong buffers and the histogram workspace in a file-scope device array.  For callers that
+// cannot call hipMalloc or size a workspace: code under HIP graph capture, tight serving loops, harnesses that forbid it.
+// Every GPU the library runs on holds its own copy of the array (kStaticSortBytes, ~8.6 MB) until the process ends.
+// ------------------------------------------------------------------------------------------
+namespace gsx {
+
+constexpr int64_t kStaticSortMaxN = GSX_STATIC_SORT_MAX_N;
+// keys_tmp | values_tmp | ws, each part 256-byte aligned (kStaticSortMaxN * 4 is)
+constexpr size_t kStaticSortWs = ((size_t)((kStaticSortMaxN + kSortTile - 1) / kSortTile) * (kRadix + 1) * 4 + 255) / 256 * 256 + (size_t)kRadix * 4;
+constexpr size_t kStaticSortBytes = 2 * (size_t)kStaticSortMaxN * 4 + kStaticSortWs;
+static __device__ __align__(256) unsigned char scratch[kStaticSortBytes];
+
+// In host code `scratch` is a stand-in, not a device address: each device's copy is looked up once, with that device
+// current, and only that pointer is ever handed to a kernel or a memory call.
+constexpr int kMaxDevices = 64;
+static std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
+static int static_scratch(void** out)
+{
+    int dev = -1;
+    GSX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return GSX_E_INVALID;
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {       // first call on this device (two threads racing here look up the same address)
+        GSX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return GSX_E_HIP;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return GSX_OK;
+}
+
+}  // namespace gsx
+
+GSX_API int gsx_sort_pairs_u32_static(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
+                                      int64_t n, int begin_bit, int end_bit, void* stream)
+{
+    if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSX_E_INVALID;
+    if (n > kStaticSortMaxN) return GSX_E_CAPACITY;            // beyond the static scratch: use gsx_sort_pairs_u32 with a workspace
+    if (n == 0) return GSX_OK;
+    if (!keys_in || !keys_out || !values_out || keys_in == keys_out) return GSX_E_INVALID;
+    void* base = nullptr;
+    const int st = static_scratch(&base);
+    if (st != GSX_OK) return st;
+    unsigned char* b = static_cast<unsigned char*>(base);
+    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(b);
+    uint32_t* values_tmp = reinterpret_cast<uint32_t*>(b + (size_t)kStaticSortMaxN * 4);
+    void* ws = b + 2 * (size_t)kStaticSortMaxN * 4;
+    // nothing in the scratch has to start at zero: every pass's histogram kernel writes each of the table entries the pass
+    // reads, and the ping-pong buffers are written before they are read
+    return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, nullptr, begin_bit, end_bit,
+                               ws, kStaticSortWs, (hipStream_t)stream, 32, nullptr);
 }

@@ -36,7 +36,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 12
+#define GSX_ABI_VERSION 13
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -68,6 +68,20 @@ int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_in,
                        uint32_t* keys_tmp, uint32_t* values_tmp,
                        int64_t n, int begin_bit, int end_bit, int check_bit, uint64_t* mismatch_dev,
                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- gsx_sort_pairs_u32 for callers that cannot allocate or size a workspace -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference (nor in its FFI: it has none).  Same
+ * kernels, same result bit for bit; the ping-pong buffers and the histogram workspace live in a device array inside the
+ * library (about 8.6 MB per GPU the library runs on, held until the process ends).  Limits and caveats:
+ *   - n <= GSX_STATIC_SORT_MAX_N, else GSX_E_CAPACITY (use gsx_sort_pairs_u32 with a workspace);
+ *   - the device that `stream` belongs to must be the CURRENT device of the calling thread;
+ *   - the first call on a device looks the array's address up (hipGetSymbolAddress: no allocation, but make that call
+ *     outside a graph capture); no call allocates or frees device memory;
+ *   - all calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race. */
+#define GSX_STATIC_SORT_MAX_N (1 << 20)
+int gsx_sort_pairs_u32_static(const uint32_t* keys_in, const uint32_t* values_in,
+                              uint32_t* keys_out, uint32_t* values_out,
+                              int64_t n, int begin_bit, int end_bit, void* stream);
 
 /* ---- exclusive prefix sum of n u32; total (u64) written to *total_dev.  ws: gsx_scan_workspace_bytes(n). */
 size_t gsx_scan_workspace_bytes(int64_t n);
