@@ -88,7 +88,44 @@ def analytic_upstream(shape):
     return np.sin(0.37 * c + 0.11 * y + 0.07 * x + 0.5 * b).astype(np.float32)
 
 
-def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, analytic=False):
+def fp64_yardstick(model, pose, H, W, n_composited, d_rgb):
+    """The reference's formulas (gaussian_splatting.py:241-257 projection, :284-292 covariances, :332-342 Jacobian,
+    :124-144 compositing, stopped after the reference's own exit index) evaluated in float64 with autograd -- the reference
+    module itself cannot run in double (its Jacobian is allocated as float32, :338).  NOT a second reference: a yardstick for
+    the reference's own float32 rounding noise.  With the default init some Gaussians have world z within a few
+    hundredths of 0; their 1/z Jacobian makes the 2x2 covariance nearly singular and the reference's float32 gradient of
+    such a Gaussian is off by up to ~1e-3 of the tensor's maximum.  A parity tolerance cannot be tighter than that."""
+    import torch.nn.functional as F
+    f64 = torch.float64
+    P = {k: getattr(model, k).detach().double().requires_grad_(True) for k in ("positions", "scales", "rotations", "opacity", "features")}
+    M = pose.double()
+    p = P["positions"]
+    cam = torch.cat([p, torch.ones(p.shape[0], 1, dtype=f64)], 1) @ M.T
+    depth, mu = cam[:, 2], cam[:, :2] / cam[:, 2:3]
+    w, x, y, z = F.normalize(P["rotations"], dim=1).unbind(1)
+    R = torch.stack([1 - 2*y*y - 2*z*z, 2*x*y - 2*w*z, 2*x*z + 2*w*y, 2*x*y + 2*w*z, 1 - 2*x*x - 2*z*z, 2*y*z - 2*w*x,
+                     2*x*z - 2*w*y, 2*y*z + 2*w*x, 1 - 2*x*x - 2*y*y], 1).reshape(-1, 3, 3)
+    RS = R @ torch.diag_embed(P["scales"])
+    J = torch.zeros(p.shape[0], 2, 3, dtype=f64)
+    J[:, 0, 0] = M[0, 0] / p[:, 2]; J[:, 1, 1] = M[1, 1] / p[:, 2]
+    J[:, 0, 2] = -M[0, 0] * p[:, 0] / p[:, 2] ** 2; J[:, 1, 2] = -M[1, 1] * p[:, 1] / p[:, 2] ** 2
+    cov2 = J @ (RS @ RS.transpose(1, 2)) @ J.transpose(1, 2)
+    order = torch.argsort(depth, descending=True)
+    gy, gx = torch.meshgrid(torch.linspace(-1, 1, H, dtype=f64), torch.linspace(-1, 1, W, dtype=f64), indexing="ij")
+    grid = torch.stack([gx, gy], -1).reshape(-1, 2)
+    C = torch.zeros(3, H * W, dtype=f64); A = torch.zeros(H * W, dtype=f64)
+    for k in range(n_composited):
+        i = order[k]
+        d = grid - mu[i]
+        inv = torch.inverse(cov2[i] + 1e-6 * torch.eye(2, dtype=f64))
+        al = torch.exp(-0.5 * ((d @ inv) * d).sum(-1)) * P["opacity"][i, 0]
+        C = C + (1 - A) * P["features"][i][:, None] * al
+        A = A + (1 - A) * al
+    (C.reshape(3, H, W) * d_rgb.double()).sum().backward()
+    return {k: v.grad.numpy() for k, v in P.items()}, order.numpy()
+
+
+def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, analytic=False, yardstick=False):
     n = model.num_gaussians
     B = poses.shape[0]
     # count the early-exit tests the reference performs
@@ -141,6 +178,12 @@ def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, 
         g_features=model.features.grad.numpy(),
         analytic_upstream=np.int32(1 if analytic else 0),
     )
+    if yardstick:
+        assert rgb_only and B == 1
+        g64, order64 = fp64_yardstick(model, poses[0], H, W, calls["n"], d_rgb[0])
+        assert np.array_equal(order64, order.numpy()), "float64 depth order differs: the yardstick would composite another scene"
+        for k in ("positions", "scales", "rotations", "opacity", "features"):
+            fx["ref_noise_" + k] = np.float64(np.abs(fx["g_" + k].astype(np.float64) - g64[k]).max() / max(np.abs(g64[k]).max(), 1e-30))
     if subsample:
         fx["out_rgb_sub"] = img[:, :, ::subsample, ::subsample].copy()
         fx["subsample"] = np.int32(subsample)
@@ -151,6 +194,8 @@ def run_case(name, model, poses, H, W, seed_up, rgb_only=False, subsample=None, 
         fx["d_rgb"] = d_rgb.numpy()
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **fx)
+    if yardstick:
+        print("   reference float32 noise vs float64 yardstick:", {k[10:]: f"{float(v):.1e}" for k, v in fx.items() if k.startswith("ref_noise_")})
     print(f"{name}: N={n} B={B} {W}x{H} composited={calls['n']} "
           f"max|rgb|={np.abs(img).max():.4f} -> {os.path.getsize(path)/1024:.0f} KiB", flush=True)
 
@@ -193,7 +238,40 @@ def run_train_case(name, model, poses, H, W, seed_target, steps=3):
     print(f"{name}: losses {losses} grad norms {norms}")
 
 
+def tilted_pose(tz, yaw_deg, tx=0.0, ty=0.0):
+    """world->camera matrix as the reference applies it (gaussian_splatting.py:250-253): a yaw about the y axis and a shift"""
+    a = np.radians(yaw_deg)
+    p = torch.eye(4)
+    p[0, 0], p[0, 2], p[2, 0], p[2, 2] = float(np.cos(a)), float(np.sin(a)), float(-np.sin(a)), float(np.cos(a))
+    p[0, 3], p[1, 3], p[2, 3] = tx, ty, tz
+    return p
+
+
+# Scenes in which the reference's GLOBAL early exit (gaussian_splatting.py:147-148) fires: its default init puts world z
+# near 0 for many Gaussians, the 1/z Jacobian makes those splats screen-sized, and every pixel saturates after a few
+# hundred of them.  (name, N, seed, pose, H, W): different sizes, seeds, image shapes and cameras, so that the exit index
+# is pinned by the reference itself and not only by the CPU restatement.
+EXIT_CASES = [
+    ("exit0_n200_32x24", 200, 40, pose_tz(3.0), 24, 32),
+    ("exit1_n400_48x32", 400, 41, pose_tz(2.5), 32, 48),
+    ("exit2_n600_64x48", 600, 42, pose_tz(3.0), 48, 64),
+    ("exit3_n800_40x40", 800, 43, pose_tz(4.0), 40, 40),
+    ("exit4_n1000_33x17", 1000, 44, pose_tz(2.0), 17, 33),
+    ("exit5_n1200_64x36", 1200, 45, tilted_pose(3.0, 20.0), 36, 64),
+    ("exit6_n1500_48x48", 1500, 46, tilted_pose(3.5, -35.0, 0.2, -0.1), 48, 48),
+    ("exit7_n2000_64x48", 2000, 47, pose_tz(3.0), 48, 64),
+    ("exit8_n500_16x16", 500, 48, tilted_pose(2.2, 10.0, -0.3, 0.2), 16, 16),
+    ("exit9_n1000_56x40", 1000, 49, tilted_pose(5.0, 60.0), 40, 56),
+    ("exit10_n300_24x32", 300, 50, pose_tz(1.5), 32, 24),
+    ("exit11_n1600_64x48", 1600, 51, tilted_pose(2.8, -15.0, 0.0, 0.3), 48, 64),
+]
+
+
 def main():
+    if "--exit-only" in sys.argv:
+        for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
+            run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
+        return
     if "--train-only" in sys.argv:
         run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
         return
@@ -214,6 +292,8 @@ def main():
     run_case("h1_w5_n8", scene_synth(8, 23, 0.05, 0.2), pose_tz(2.0)[None], 1, 5, 111)
     run_case("odd_33x17_n120", scene_synth(120, 24, 0.01, 0.08), pose_tz(1.5)[None], 17, 33, 112)
     run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
+    for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
+        run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
     if big:
         # BASELINE config 1: 5000 default-init Gaussians, 400x300 (README.md:85-94); ~16 GB RSS, ~10 s
         run_case("config1_5000_400x300", scene_default(5000, 0), I3, 300, 400, 0,

@@ -204,6 +204,7 @@ def test_trainer_three_steps_match_reference(fused):
     m = m.to(dev)
     opt = make_optimizer(m, fused_clip_norm=0.1 if fused else None, write_clipped_grad=True)
     poses = torch.from_numpy(fx["poses"]).to(dev); target = torch.from_numpy(fx["target"]).to(dev)
+    report = {}
     for s in range(int(fx["steps"])):
         loss = train_step(m, opt, poses, target, reference_regularised_mse, max_grad_norm=0.1)
         assert abs(float(loss) - fx["losses"][s]) <= 1e-5 * abs(fx["losses"][s]), (s, float(loss), fx["losses"][s])
@@ -216,6 +217,13 @@ def test_trainer_three_steps_match_reference(fused):
             lr = DEFAULT_LRS[k]
             assert np.quantile(d, 0.99) <= 0.02 * lr, (s, k, float(np.quantile(d, 0.99)), lr)
             assert d.max() <= (s + 1) * lr * 1.01, (s, k, float(d.max()))
+            # the bound above is vacuous for Adam (nothing moves further than lr per step), so: EVERY element whose
+            # reference gradient is well above Adam's eps (1e-8) -- where the update -lr g / (|g| + eps) is a well-conditioned
+            # function of the gradient -- must land within 2 % of lr per step of the reference's parameter
+            wc = np.abs(fx["clipped_g_" + k]).ravel() > 1e-6
+            report[(s, k)] = (float(wc.mean()), float(d[wc].max() / lr) if wc.any() else 0.0)
+            assert d[wc].max() <= 0.02 * lr * (s + 1), (s, k, report[(s, k)])
+    assert np.mean([v[0] for v in report.values()]) > 0.5, report          # ... and that is most of the elements
 
 
 def test_maintenance_kernels_match_cpu():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (golden_names, load_golden, rel_err, rgb_err, RGB_TOL, GRAD_RTOL, PARAMS,
+from helpers import (golden_names, load_golden, rel_err, elem_rel_err, l2_rel_err, grad_tol, rgb_err, RGB_TOL, GRAD_RTOL, PARAMS,
                      synth_scene, default_scene, pose_tz, orbit_pose)
 
 pytestmark = pytest.mark.gpu
@@ -76,6 +76,42 @@ def gpu_backward(gp, H, W, d_rgb, d_mean2d=None, d_depth=None, d_cov=None):
     R.backward_view(t["P"], vs, cv(d_rgb), cv(d_mean2d), cv(d_depth), cv(d_cov), grads, accumulate=False)
     torch.cuda.synchronize()
     return {k: g.cpu().numpy() for k, g in zip(PARAMS, grads)}
+
+
+# Per-element view of the gradient error: the tensor-level figure max|d| / max|ref| lets a mid-sized
+# element be far off.  Two more figures per tensor, asserted and written to gpurun_out/r2_grad_errors.json:
+#   L2-relative  |g - ref|_2 / |ref|_2                                                   bound ELEM_L2_TOL
+#   per-element  max over elements with |ref| > 1e-3 max|ref| of |g - ref| / |ref|        bound ELEM_REL_TOL
+# The per-element bound cannot be 1e-3: an element at the floor is 1000x smaller than the sums of +/- terms it is the
+# float32 remainder of (the reference's own float32 result has the same property against a float64 evaluation).
+# Measured over all fixtures and full-size cases (r2): L2 <= 7e-5 and per-element <= 6.5e-3 everywhere except exit8 (the
+# fixture with a near-singular Gaussian, 8.8e-4 and 1.8e-2) -- and the ORACLE's per-element figure against the reference is
+# the same size (up to 8e-3): that is the reference's float32 noise floor on small elements, not this path's.
+ELEM_L2_TOL = 2e-4           # + 2 x the reference's recorded float32 noise for the tensor (exit8 only)
+ELEM_REL_TOL = 1e-2          # x (1 + 2 x noise / 1e-3)
+_GRAD_REPORT = {}
+
+
+def check_elementwise(case, k, g, ref, oracle=None, fx=None):
+    import json, os
+    row = {"tensor_rel_vs_ref": rel_err(g, ref), "l2_rel_vs_ref": l2_rel_err(g, ref)}
+    row["elem_rel_vs_ref"], row["elements_above_floor"] = elem_rel_err(g, ref)
+    if oracle is not None:
+        row["l2_rel_vs_oracle"] = l2_rel_err(g, oracle)
+        row["elem_rel_vs_oracle"], _ = elem_rel_err(g, oracle)
+        row["oracle_elem_rel_vs_ref"], _ = elem_rel_err(oracle, ref)
+    if fx is not None and ("ref_noise_" + k) in fx:
+        row["ref_float32_noise"] = float(fx["ref_noise_" + k])
+    _GRAD_REPORT.setdefault(case, {})[k] = row
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "r2_grad_errors.json"), "w") as f:
+            json.dump(_GRAD_REPORT, f, indent=1)
+    except OSError:
+        pass
+    noise = float(fx.get("ref_noise_" + k, 0.0)) if fx is not None else 0.0
+    assert row["l2_rel_vs_ref"] < ELEM_L2_TOL + 2.0 * noise, (case, k, row)
+    assert row["elem_rel_vs_ref"] < ELEM_REL_TOL * (1.0 + 2.0 * noise / GRAD_RTOL), (case, k, row)
 
 
 def assert_integer_products_equal(gp, fw):
@@ -167,8 +203,11 @@ def test_golden_forward_backward(dev, O, name):
     go = O.backward(fx["params"], fx["poses"][0], H, W, fw, fx["d_rgb"][0], fx["d_pos2d"][0], fx["d_depths"][0],
                     fx["d_cov2d"][0], "tiled")
     for k in PARAMS:
-        assert rel_err(g[k], fx["g_" + k]) < GRAD_RTOL, f"{k} vs reference"
-        assert rel_err(g[k], go[k]) < GRAD_RTOL, f"{k} vs oracle"
+        assert rel_err(g[k], fx["g_" + k]) < grad_tol(fx, k), f"{k} vs reference"
+        # vs the oracle (float64 accumulation: within 4e-5 of the float64 yardstick on every fixture) the float32 kernels are
+        # allowed the noise the reference's own float32 run shows on the same scene (non-zero for exit8 only, see grad_tol)
+        assert rel_err(g[k], go[k]) < GRAD_RTOL + float(fx.get("ref_noise_" + k, 0.0)), f"{k} vs oracle"
+        check_elementwise(name, k, g[k], fx["g_" + k], go[k], fx)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -269,7 +308,7 @@ def test_module_dropin_matches_reference_outputs(dev):
     assert m.last_n_composited() == [int(fx["n_composited"])]
     assert rgb_err(out["rendered_images"][0].detach().cpu().numpy(), fx) < RGB_TOL
     for k in PARAMS:
-        assert rel_err(getattr(m, k).grad.cpu().numpy(), fx["g_" + k]) < GRAD_RTOL, k
+        assert rel_err(getattr(m, k).grad.cpu().numpy(), fx["g_" + k]) < grad_tol(fx, k), k
     # the depth map is an extra (the reference returns none): off by default, same image with it on
     assert "depth_map" not in out
     m.render_depth_map = True
@@ -501,6 +540,68 @@ def test_full_size_vs_oracle(dev, O, case):
     go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
     for k in PARAMS:
         assert rel_err(g[k], go[k]) < GRAD_RTOL, k
+        check_elementwise("full_size_" + case, k, g[k], go[k])
+
+
+def test_config5_full_size_properties(dev):
+    """BASELINE config 5 AT ITS OWN SIZE: 6 M Gaussians with splats of up to ~100 px and depths quantised to 2^-6 (ties) on
+    1920x1080 = 8160 tiles (the generic two-pass tile sort), orbit view 1: 44.7 M (tile, Gaussian) instances.  The oracle
+    would need minutes here, so the bar is the size-independent properties (as test_full_size_properties for config 3):
+    a permutation in descending depth with ties by index, strictly sorted unique 64-bit keys, ranges that partition [0, D),
+    instances inside their Gaussian's box, a finite image, bitwise determinism of image and gradients, and the module
+    (one-call path, asynchronous count, capacity-sized launches) equal to the staged path bit for bit."""
+    from gaussian_splatting_amd.scenes import config_scene
+    from gaussian_splatting_amd import GaussianSplat
+    params, H, W = config_scene("c5")
+    n = params["positions"].shape[0]
+    assert (n, H, W) == (6_000_000, 1080, 1920)
+    pose = orbit_pose(1)
+    gp = gpu_pipeline(params, pose, H, W, dev)
+    D = gp["D"]
+    assert 40_000_000 < D < 50_000_000, D
+    order = gp["order"]
+    seen = np.zeros(n, np.uint8); seen[order] = 1
+    assert seen.all()                                                                     # a permutation
+    d = gp["depth"][order]
+    assert np.all(d[:-1] >= d[1:])                                                        # descending depth ...
+    tie = d[:-1] == d[1:]
+    assert tie.sum() > 1_000_000 and np.all(order[:-1][tie] < order[1:][tie])             # ... ties (2.15 M of them in this view) by index
+    keys = (gp["tiles"].astype(np.uint64) << np.uint64(32)) | gp["ranks"].astype(np.uint64)
+    assert np.all(keys[:-1] < keys[1:])                                                   # strictly sorted, unique
+    del keys
+    r = gp["ranges"]
+    assert r.shape[0] == 8160 and r[0, 0] == 0 and r[-1, 1] == D and np.all(r[1:, 0] == r[:-1, 1])
+    assert D == int(gp["tiles_touched"].astype(np.uint64).sum())
+    t_of = np.repeat(np.arange(r.shape[0], dtype=np.uint32), (r[:, 1] - r[:, 0]).astype(np.int64))
+    assert np.array_equal(t_of, gp["tiles"])
+    # every instance lies inside its Gaussian's footprint box (record words 10, 11: pixel box, rank order)
+    box = gp["rec"].view(np.uint32)[:, 10:12][gp["ranks"]]
+    tw = (W + 15) // 16
+    tx, ty = gp["tiles"] % tw, gp["tiles"] // tw
+    assert np.all((tx >= (box[:, 0] & 0xffff) >> 4) & (tx <= (box[:, 0] >> 16) >> 4) & (ty >= (box[:, 1] & 0xffff) >> 4) & (ty <= (box[:, 1] >> 16) >> 4))
+    del box, tx, ty, t_of
+    assert np.isfinite(gp["rgb"]).all() and gp["alpha"].min() >= 0 and gp["alpha"].max() <= 1 + 1e-5
+    d_rgb = np.random.default_rng(3).standard_normal((3, H, W)).astype(np.float32)
+    g1 = gpu_backward(gp, H, W, d_rgb)
+    rgb1 = gp["rgb"]
+    del gp
+    torch.cuda.empty_cache()
+    gp2 = gpu_pipeline(params, pose, H, W, dev)
+    g2 = gpu_backward(gp2, H, W, d_rgb)
+    assert np.array_equal(rgb1, gp2["rgb"])
+    for k in PARAMS:
+        assert np.array_equal(g1[k], g2[k]), k
+        assert np.isfinite(g1[k]).all() and np.abs(g1[k]).max() > 0
+    del gp2, g2
+    torch.cuda.empty_cache()
+    m = GaussianSplat(n)
+    m.load_state_dict({k: torch.from_numpy(params[k]) for k in PARAMS})
+    m = m.to(dev)
+    out = m(torch.from_numpy(pose).to(dev)[None], (H, W))
+    assert np.array_equal(out["rendered_images"][0].detach().cpu().numpy(), rgb1)
+    (out["rendered_images"][0] * torch.from_numpy(d_rgb).to(dev)).sum().backward()
+    for k in PARAMS:
+        assert np.array_equal(getattr(m, k).grad.cpu().numpy(), g1[k]), k
 
 
 # ---------------------------------------------------------------------------------------------

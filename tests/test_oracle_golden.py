@@ -3,7 +3,7 @@ reference itself (tests/golden/make_golden.py).  This is what pins the oracle.""
 import numpy as np
 import pytest
 from oracle import gsx_oracle as O
-from helpers import golden_names, load_golden, rel_err, rgb_err, RGB_TOL, GRAD_RTOL, PARAMS
+from helpers import golden_names, load_golden, rel_err, rgb_err, grad_tol, RGB_TOL, GRAD_RTOL, PARAMS
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -54,7 +54,7 @@ def test_render_and_grads(name, mode):
     g = O.backward(fx["params"], fx["poses"][0], H, W, fw, fx["d_rgb"][0], fx["d_pos2d"][0],
                    fx["d_depths"][0], fx["d_cov2d"][0], mode)
     for k in PARAMS:
-        assert rel_err(g[k], fx["g_" + k]) < GRAD_RTOL, k
+        assert rel_err(g[k], fx["g_" + k]) < grad_tol(fx, k), k
 
 
 def test_tiled_products_consistent():
