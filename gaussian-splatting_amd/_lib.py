@@ -22,7 +22,7 @@ SYMBOLS = [
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
 ]
 
-ABI_VERSION = 13            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 14            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12

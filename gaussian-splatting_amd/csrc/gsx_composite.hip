@@ -173,13 +173,202 @@ __global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward occlusion skipping.  The chunk pass composites all chunks of a tile in parallel, blind to the transmittance in
+// front of them; in a dense view a third to a half of the instances sit behind a wall of earlier splats (and in a
+// config-5-like scene nine tenths).  Every chunk therefore PUBLISHES, when it is done,
+//   * a payload: per pixel, the DARKNESS q = floor(-4 log2 |T_local|) of what it lets through, in quarter-bits, rounded
+//     towards "brighter" (one byte per pixel: 64 words per chunk, lane l holds its own four pixels), and
+//   * a header: the chunk's bound on how much |T| can GROW inside it, in quarter-bits (0 unless an opacity lies outside
+//     [0, 2]; a NaN/inf transmittance or a bound above 15 bits makes the chunk UNBOUNDED).
+// Integer sums of the payloads of a tile's chunks 0..k-1 bound -log2 |T| on entry to chunk k, per pixel.  The rule, per
+// 8x8 QUADRANT w of the tile (64 pixels = one wave of the combine pass = one lane-quadruple slot of the chunk pass):
+//   dark(c, w)  <=>  no unbounded chunk before c  and  every pixel p of w has  sum_c(p) >= 4 GSX_CUT_LOG2 + growth(c)
+//   sum_{c+1}(p) = sum_c(p) - growth(c)   if dark(c, w)      (whatever the chunk would have done there, it cannot have
+//                = sum_c(p) + q_c(p)      otherwise           raised |T| by more than its growth bound)
+// In a dark quadrant every weight T * alpha is below 2^-GSX_CUT_LOG2, the bound under which the footprint cut drops pairs.
+// The combine pass evaluates the recursion from the published words -- integers, a function of the data alone -- and
+// treats a dark quadrant of a chunk as the identity WHETHER OR NOT it was computed, so the image does not depend on timing.
+// A chunk may therefore leave out every quadrant it can PROVE dark from what is published when it starts (the same
+// recursion over the chunks in front of it; a quadrant that is not dark needs the payload of that chunk, a dark one only
+// its header), and skip itself when all four are.  Payloads of chunks in front of a dark point always exist: a quadrant
+// that is not dark is always computed.  Workgroups are dispatched in LEVEL order (every tile's chunk 0, then every tile's
+// chunk 1, ...; chunk_order_kernel builds the table), so that by the time the deep chunks of a tile start, its shallow ones
+// have finished.  No waiting anywhere: a chunk that cannot tell yet computes.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kHdrDone = 0x80000000u, kHdrUnbounded = 0x40000000u, kHdrGrowthMask = 0xFFFFFu;
+constexpr int kDarkQ = 4 * GSX_CUT_LOG2;               // quarter-bits of darkness at which every weight is below the cut
+constexpr int kPayBias = 65;                           // payload byte = q + 65 in [1, 255] (0 = not published): q in [-64, 190]
+// tail of the chunk-state buffer behind the states, in words per chunk: meta 1, dark 1, work lists 2 x kWorkClasses (+ 16
+// counters), header 1, order table 1, payload 64
+__device__ __host__ __forceinline__ size_t tail_hdr_offset(size_t max_chunks) { return 2 * max_chunks + 16 + 2 * (size_t)kWorkClasses * max_chunks; }
+
+// one splat's contribution to its chunk's growth bound (bits): log2 |1 - o| for an opacity outside [0, 2] (+ slack for the
+// rounding of the sum); NaN stays NaN
+// a = (mu_x, mu_y, k00, kb), b = (k11, opacity, ...) of the record.  A splat whose exponent is not a proper (negative
+// definite, finite) quadratic can reach exp2(q) = inf -- a Gaussian at the camera plane -- and bounds nothing: infinite.
+// A function of the RECORD alone, so that a chunk that skips itself and one that computes agree on the header.
+__device__ __forceinline__ float growth_term(const float4& a, const float4& b)
+{
+    const bool proper = (a.z < 0.0f) && (b.x < 0.0f) && (4.0f * a.z * b.x - a.w * a.w > 0.0f) && (fabsf(a.x) <= 3.0e38f) && (fabsf(a.y) <= 3.0e38f);
+    if (!proper) return __builtin_inff();
+    const float o = b.y;
+    return (o >= 0.0f && o <= 2.0f) ? 0.0f : __builtin_amdgcn_logf(fabsf(o - 1.0f)) + 1e-3f;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// header word of a finished chunk from its growth sum (wave total; NaN or 15 bits and more: unbounded)
+__device__ __forceinline__ uint32_t header_word(float growth)
+{
+    if (!(growth < 15.0f)) return kHdrDone | kHdrUnbounded;
+    return kHdrDone | (growth == 0.0f ? 0u : (uint32_t)(4.0f * growth) + 2u);
+}
+// darkness of one pixel's local transmittance (m, e) after renormalisation (|m| in [0.5, 1) or 0), rounded down
+__device__ __forceinline__ int darkness_q(float m, int e)
+{
+    const float am = fabsf(m);
+    if (!(am < 1.0f)) return -64;              // not finite: only in a chunk whose header says unbounded
+    if (am == 0.0f) return 190;
+    const int q = (int)floorf(-4.0f * ((float)e + __builtin_amdgcn_logf(am)) - 0.05f);
+    return max(-64, min(190, q));
+}
+
+// Entry darkness of chunk k of a tile from what is published NOW: s[w] = this lane's pixel of quadrant w.  false = cannot
+// tell (a chunk in front has not finished, or is unbounded): the caller computes everything.
+// returns 0, or why not: 2 = a header is missing or unbounded, 3 = a needed payload is missing (kept in the low byte of the
+// chunk's meta word as a diagnostic: tools/skip_stats.py)
+__device__ __forceinline__ int entry_darkness(const uint32_t* hdr_t, const uint32_t* pay_t, uint32_t k, int lane, int s[4])
+{
+    s[0] = s[1] = s[2] = s[3] = 0;
+    for (uint32_t base = 0; base < k; base += 64) {
+        const uint32_t idx = base + (uint32_t)lane;
+        const uint32_t hv = idx < k ? __hip_atomic_load(hdr_t + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kHdrDone;
+        if (__builtin_amdgcn_ballot_w64(hv == 0u || (hv & kHdrUnbounded))) return 2;
+        const uint32_t cnt = min(64u, k - base);
+        // no grower among these chunks and all four quadrants dark already: they are all dark and change nothing
+        if (!__builtin_amdgcn_ballot_w64((hv & kHdrGrowthMask) != 0u) &&
+            !__builtin_amdgcn_ballot_w64(s[0] < kDarkQ || s[1] < kDarkQ || s[2] < kDarkQ || s[3] < kDarkQ)) continue;
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
+            uint32_t pw[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)            // eight payloads in flight (most are needed: the dark point is rarely far)
+                pw[u] = (j0 + u < cnt) ? __hip_atomic_load(pay_t + (size_t)(base + j0 + u) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (j0 + u < cnt) {
+                    const int gq = (int)((uint32_t)__shfl((int)hv, (int)(j0 + u), 64) & kHdrGrowthMask);
+                    const int thr = kDarkQ + gq;
+                    bool d[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) d[w] = __builtin_amdgcn_ballot_w64(s[w] < thr) == 0ull;
+                    if (!(d[0] && d[1] && d[2] && d[3]) && __builtin_amdgcn_ballot_w64(pw[u] == 0u)) return 3;   // not finished yet
+#pragma unroll
+                    for (int w = 0; w < 4; w++) s[w] = d[w] ? s[w] - gq : s[w] + (int)((pw[u] >> (8 * w)) & 0xffu) - kPayBias;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// The part of the chunk pass that only a DEEP view runs: publishes the chunk's header, then tries to prove quadrants dark.
+// Returns dark quadrants (bits 0..3) | reason code << 8.
+__device__ __forceinline__ uint32_t deep_prologue(const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, uint32_t cb, uint32_t chunk,
+                                               uint32_t begin, uint32_t end, uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pay, int lane)
+{
+    const uint32_t level = chunk - cb;
+    // The header goes out FIRST: a chunk's growth bound is a function of its records alone (same terms, same order as the
+    // staging loop of the chunk pass), and it is all that a later chunk needs of a DARK one -- which may still be running,
+    // or be skipping itself, when that later chunk starts.  Payloads are only needed of chunks in front of the dark point.
+    float pre = 0.0f;
+    for (uint32_t i = begin + lane; i < end; i += kCBatch) {
+        const float4* R = rec + (size_t)3 * ranks[i];
+        pre += growth_term(R[0], R[1]);
+    }
+    const uint32_t hw = header_word(wave_sum(pre));
+    if (lane == 0) __hip_atomic_store(hdr + chunk, hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ds[4];
+    uint32_t why = level == 0 ? 1u : (hw & kHdrUnbounded) ? 2u : (uint32_t)entry_darkness(hdr + cb, pay + (size_t)cb * 64, level, lane, ds);
+    uint32_t dark_quads = 0;
+    if (why == 0u) {
+        const int thr = kDarkQ + (int)(hw & kHdrGrowthMask);
+#pragma unroll
+        for (int w = 0; w < 4; w++) dark_quads |= (__builtin_amdgcn_ballot_w64(ds[w] < thr) == 0ull) ? (1u << w) : 0u;
+        why = dark_quads ? 5u : 4u;                           // 4 = no quadrant is dark enough, 5 = some are (left out)
+    }
+    return dark_quads | (why << 8);
+}
+
+// Level-order work table: order_tab[i] = chunk id, all tiles' chunk 0 first (tile order), then all chunk 1s, ...  Workgroup l
+// writes level l: its offset is sum_t min(n_t, l), a tile's slot its rank among the tiles that reach the level.  The last
+// workgroup takes every level from kOrderLevels - 1 on, tile by tile.  Also clears the published headers and payloads.
+constexpr int kOrderThreads = 1024, kOrderLevels = 256;
+// Skipping pays where a tile's list is many rounds of the machine deep: then the chunks that decide a tile's dark point have
+// long finished when its deep chunks start.  In a shallow view (config 3: <= 10 k chunks on ~5 k wave slots, dark points
+// at level 15-20, i.e. exactly one round deep) the deep chunks start while the shallow ones still run, nothing can be
+// proven in time, and reading the predecessors' payloads only costs (measured: +25 % on the chunk pass, no chunk skipped).
+// A view is DEEP from this many chunks on (a function of the data, like everything the rule depends on); below it nothing is
+// published, nothing skipped, and the combine pass ignores the rule.
+constexpr uint32_t kDeepChunks = 20480;
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kOrderThreads / 64; w++) { const uint32_t x = s_w[w]; if (w < wave) base += x; tot += x; }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kOrderThreads) void chunk_order_kernel(const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t max_chunks,
+                                                                    uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay,
+                                                                    uint32_t* __restrict__ order_tab)
+{
+    __shared__ uint32_t s_w[kOrderThreads / 64];
+    const uint32_t l = blockIdx.x, n_chunks = min(chunk_base[n_tiles], max_chunks);
+    if (n_chunks < kDeepChunks) return;                       // a shallow view: no table, and every word is written before it is read
+    // "not published": headers and payloads of this view's chunks (not of the buffers' capacity)
+    for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_chunks; i += (size_t)gridDim.x * kOrderThreads) hdr[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_chunks * 64; i += (size_t)gridDim.x * kOrderThreads) pay[i] = 0u;
+    const bool tail = blockIdx.x == gridDim.x - 1;
+    uint32_t below = 0;                                       // chunks of the levels before l
+    for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
+        const int t = t0 + (int)threadIdx.x;
+        if (t < n_tiles) below += min(chunk_base[t + 1] - chunk_base[t], l);
+    }
+    uint32_t level_off;
+    block_excl_scan_1024(below, s_w, &level_off);
+    if (level_off >= n_chunks) return;                        // no tile is this deep (uniform)
+    uint32_t carry = level_off;
+    for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
+        const int t = t0 + (int)threadIdx.x;
+        uint32_t cb = 0, cnt = 0;
+        if (t < n_tiles) { cb = chunk_base[t]; const uint32_t n = chunk_base[t + 1] - cb; cnt = n > l ? (tail ? n - l : 1u) : 0u; }
+        uint32_t tot;
+        const uint32_t pos = carry + block_excl_scan_1024(cnt, s_w, &tot);
+        for (uint32_t j = 0; j < cnt; j++) order_tab[pos + j] = cb + l + j;
+        carry += tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // F1: one wave per chunk, local compositing from (C = 0, T = 1)
 // ------------------------------------------------------------------------------------------
 template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t N, int H, int W, int tw, float stepx, float stepy,
-    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work)
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
+    uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay, const uint32_t* __restrict__ order_tab)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_rank[kCBatch];
@@ -195,8 +384,27 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     // launched with a small fixed grid -- an unsaturated view pays for a few hundred early returns, not for max_chunks of
     // them -- and walks the chunks with a grid stride when it does run.
     for (uint32_t blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
-    const uint32_t chunk = chunk_of_block(blk, n_chunks);
+    // pass 0 of a deep view walks the chunks in level order (the table of chunk_order_kernel); otherwise the stride walk
+    const bool deep = !PASS1 && n_chunks >= kDeepChunks;
+    const uint32_t chunk = deep ? order_tab[blk] : chunk_of_block(blk, n_chunks);
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    // quadrants proven dark on entry: left out (the combine pass ignores them anyway).  The zero comes out of an asm
+    // statement so that the compiler does not know it: knowing it, it clones the whole compositing loop for shallow views
+    // (twice the code, and measurably slower for both).
+    uint32_t dark_quads, why = 0;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(dark_quads));
+    if (deep) {
+        const uint32_t pre = deep_prologue(rec, ranks, chunk_base[g.tile], chunk, g.begin, g.end, hdr, pay, lane);
+        dark_quads = pre & 0xFu; why = pre >> 8;
+        if (dark_quads == 0xFu) {                             // every quadrant dark on entry: nothing to do
+            if (lane == 0) chunk_meta[chunk] = 0u;
+            return;
+        }
+    }
+    // (wave-uniform by construction -- ballots -- but the compiler cannot see that: without the scalar copy the per-splat
+    // quadrant tests become exec-mask branches instead of scalar bit tests, +25 % on this kernel)
+    dark_quads = __builtin_amdgcn_readfirstlane(dark_quads);
+    why = __builtin_amdgcn_readfirstlane(why);
     const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
     float gx[2], gy[2];
     gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
@@ -220,7 +428,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
             const float4 a = R[0], b = R[1];
-            if (!(b.y >= 0.0f && b.y <= 2.0f)) growth += __builtin_amdgcn_logf(fabsf(b.y - 1.0f)) + 1e-3f;     // NaN stays NaN
+            growth += growth_term(a, b);
             float4 c = R[2];
             c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
@@ -230,8 +438,8 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         for (uint32_t j = 0; j < cnt; j++) {
             if (PASS1) { if (s_rank[j] >= limit) { stop = true; break; } }
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z));
-            if (mk == 0u) continue;                           // inside the tile's box but outside the ellipse
+            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z)) & ~dark_quads;
+            if (mk == 0u) continue;                           // inside the tile's box but outside the ellipse (or behind the wall)
             cost += (uint32_t)__builtin_popcount(mk);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -252,9 +460,12 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         }
         __syncthreads();
     }
+    const bool publish = n_chunks >= kDeepChunks;            // (pass 1 of a deep view republishes what it recomputed)
+    uint32_t payload = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         renorm(m[k], e[k]);
+        if (publish) payload |= (uint32_t)(darkness_q(m[k], e[k]) + kPayBias) << (8 * k);
         const int pix = k * 64 + lane;
         *state_ptr(chunk_state, chunk, 0, pix) = C0[k];
         *state_ptr(chunk_state, chunk, 1, pix) = C1[k];
@@ -263,11 +474,16 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         *state_ptr(chunk_state, chunk, 4, pix) = __int_as_float(e[k]);
         *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) growth += __shfl_xor(growth, d, 64);
+    growth = wave_sum(growth);
     // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
     const uint32_t gbits = (growth == 0.0f) ? 0u : (growth < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)growth + 2u : (uint32_t)GSX_META_GROWTH_MAX;
-    if (lane == 0) chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT);
+    // publish: payload (every lane its own word), then the header.  A reader that finds the header takes the payload's
+    // word for what it is: zero = not there yet.
+    if (publish) __hip_atomic_store(pay + (size_t)chunk * 64 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+        chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT) | why;
+        if (publish) __hip_atomic_store(hdr + chunk, header_word(growth), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!PASS1) break;                        // compile-time: pass 0 has no back edge
     __syncthreads();
     }
@@ -283,7 +499,8 @@ template <bool PASS1, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
-    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, uint32_t max_chunks, int n_tiles,
+    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pay,
+    uint32_t max_chunks, int n_tiles,
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
@@ -300,8 +517,15 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     __shared__ uint8_t s_dark[kCombineBatch][4];
     // the last batch's local results stay in registers for the backward scan (most tiles have one batch)
     float l0[kCombineBatch], l1[kCombineBatch], l2[kCombineBatch], l3[kCombineBatch], l4[kCombineBatch];
+    // "Forward occlusion skipping": this pixel's darkness sum over the chunks in front, and whether an unbounded chunk has
+    // been passed (nothing is dark behind one).  One wave = one 8x8 quadrant, so the quadrant's verdict is a ballot.
+    // Only in a DEEP view (kDeepChunks: a function of the view's chunk count): shallow views neither publish nor skip.
+    int dsum = 0;
+    bool blocked = chunk_base[n_tiles] < kDeepChunks;
+    uint32_t skipped = 0;                     // bit u: this quadrant of chunk u of the (last) batch is dark -- the identity, computed or not
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l5[kCombineBatch];
+        skipped = 0;
 #pragma unroll
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = min(cb + u, c1 - 1);
@@ -314,6 +538,25 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = cb + u;
             if (c < c1) {
+                int gq = 0;
+                bool qdark = false;
+                if (!blocked) {
+                    const uint32_t hw = hdr[c];
+                    gq = (int)(hw & kHdrGrowthMask);
+                    if (hw & kHdrUnbounded) blocked = true;
+                    else qdark = __builtin_amdgcn_ballot_w64(dsum < kDarkQ + gq) == 0ull;
+                }
+                if (qdark) {                                  // the identity here, whether or not the chunk pass computed it
+                    dsum -= gq;
+                    skipped |= 1u << u;
+                    if (need_bwd && (threadIdx.x & 63) == 0) {
+                        reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = 0x81;      // dark (bit 0), by this rule (bit 7)
+                        s_dark[u][threadIdx.x >> 6] = 1;
+                    }
+                    continue;
+                }
+                // not dark: the chunk pass computed this quadrant and published what it lets through
+                if (!blocked) dsum += (int)((pay[(size_t)c * 64 + (threadIdx.x & 63)] >> (8 * (threadIdx.x >> 6))) & 0xffu) - kPayBias;
                 if (need_bwd) {
                     // occlusion cut: byte w of chunk_dark[c] = 1 when every pixel of quadrant w (this wave's 64 pixels)
                     // enters chunk c with |T| < 2^-(GSX_CUT_LOG2 + growth bits of c) (|m| < 1 after renorm, so a test
@@ -394,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 #pragma unroll
         for (int u = kCombineBatch - 1; u >= 0; u--) {
             const uint32_t c = cbl + u;
-            if (c < c1) {
+            if (c < c1 && !(skipped & (1u << u))) {
                 const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
                 *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
                 B0 = l0[u] + Tl * B0; B1 = l1[u] + Tl * B1; B2 = l2[u] + Tl * B2;
@@ -410,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             }
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
-                if (ce - c0 > (uint32_t)u) {
+                if (ce - c0 > (uint32_t)u && reinterpret_cast<const uint8_t*>(chunk_dark + (ce - 1 - u))[threadIdx.x >> 6] != 0x81) {   // (dark by the rule: the identity)
                     const uint32_t c = ce - 1 - u;
                     const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
                     *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
@@ -701,25 +944,30 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
+    uint32_t* hdr = meta + tail_hdr_offset((size_t)max_chunks);                             // published headers, level-order table, payloads
+    uint32_t* order_tab = hdr + max_chunks;
+    uint32_t* pay = order_tab + max_chunks;
     if (max_chunks <= 0) clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // otherwise block 0 of the chunk pass clears them
+    else if ((uint64_t)max_chunks >= kDeepChunks)           // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
+        chunk_order_kernel<<<dim3(kOrderLevels), dim3(kOrderThreads), 0, st>>>(chunk_base, n_tiles, (uint32_t)max_chunks, hdr, pay, order_tab);
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     } else {
-        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
-            chunk_fwd_kernel<true, true><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-            tile_combine_kernel<true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            chunk_fwd_kernel<true, true><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+            tile_combine_kernel<true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         } else {
-            chunk_fwd_kernel<true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work);
-            tile_combine_kernel<true, false><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            chunk_fwd_kernel<true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+            tile_combine_kernel<true, false><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         }
     }
     GSX_LAUNCH_CHECK();

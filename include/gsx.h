@@ -36,7 +36,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 13
+#define GSX_ABI_VERSION 14
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,

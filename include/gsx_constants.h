@@ -72,8 +72,12 @@
 #define GSX_META_COST_MASK 0xFFFFu
 #define GSX_META_GROWTH_SHIFT 24
 #define GSX_META_GROWTH_MAX 255
-/* floats the chunk-state buffer needs for max_chunks chunks (states, flags, dark bytes, work lists) */
-#define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + 12) + 16)
+/* Behind the work lists: what the chunk pass PUBLISHES per chunk when it is done -- a header word (the chunk's bound on the
+ * growth of |T| in quarter-bits, or "unbounded") and 64 payload words (per pixel, one byte: floor(-4 log2 |T_local|) + 65) --
+ * and the level-order dispatch table of the chunk pass (gsx_composite.hip, "Forward occlusion skipping").
+ * floats the chunk-state buffer needs for max_chunks chunks: states, then per chunk 1 flag word, 1 of dark bytes, 10 of work
+ * lists (+ 16 counters), 1 header, 1 table entry, 64 of payload */
+#define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + 78) + 16)
 
 /* the depth sort may skip its last pass (key bits 24..31) while those bits are the same for every Gaussian; the sort
  * counts the keys that break that assumption (gsx_sort_pairs_u32's check_bit) */
