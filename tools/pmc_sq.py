@@ -19,7 +19,7 @@ for k in a:
     row["launches"] = len(next(iter(a[k].values())))
     out[k] = row
 order = sorted(out, key=lambda k: -out[k].get("SQ_INSTS_VALU", 0))
-res = {"_method": "rocprofv3 --pmc, two passes (tools/pmc_sq.sh) over `python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline`, final round-1 build, c3 scene; "
+res = {"_method": "rocprofv3 --pmc, two passes (tools/pmc_sq.sh) over `python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline`, round-2 build (cut 2^-20), c3 scene; "
                   "per-launch averages summed over the chip. SQ_INSTS_* count wave-level instructions; a wave64 VALU instruction occupies its SIMD's issue port for "
                   "4 cycles; 256 CUs x 4 SIMDs. valu_issue_share = SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024) (the counter is summed over the 8 XCDs: 5.42 M for the 281-us backward = 8 x 678 k cycles at 2.4 GHz): the share of all VALU issue slots of the chip "
                   "that the kernel filled while it ran (GRBM_GUI_ACTIVE = cycles the kernel kept the GPU busy, as rocprofv3 reports it per dispatch).",
