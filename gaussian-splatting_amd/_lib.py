@@ -20,9 +20,10 @@ SYMBOLS = [
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd", "gsx_image_loss_fwd_grad",
     "gsx_l1_ssim_workspace_bytes", "gsx_l1_ssim_fwd", "gsx_l1_ssim_bwd",
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
+    "gsx_merge_workspace_bytes", "gsx_merge_count", "gsx_merge_fill", "gsx_merge_greedy_host",
 ]
 
-ABI_VERSION = 14            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 15            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -88,6 +89,10 @@ def lib():
     L.gsx_keep_flags.argtypes = [_p, _i32, C.c_float, _p, _p]
     L.gsx_compact_rows.argtypes = [_p, _p, _p, _i32, _i32, _p, _p]
     L.gsx_clamp_inplace.argtypes = [_p, _i64, C.c_float, C.c_float, _p]
+    L.gsx_merge_workspace_bytes.argtypes = [_i32]; L.gsx_merge_workspace_bytes.restype = C.c_size_t
+    L.gsx_merge_count.argtypes = [_p, _i32, C.c_float, _p, _p, C.c_size_t, _p]
+    L.gsx_merge_fill.argtypes = [_p, _i32, C.c_float, _p, _p, _p, C.c_size_t, _p]
+    L.gsx_merge_greedy_host.argtypes = [_i32, _p, _p, _p, _p, _p, _p]
     L.gsx_image_loss_workspace_bytes.restype = _sz
     L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
     L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]

@@ -178,8 +178,13 @@ class GaussianSplat(nn.Module):
     def merge_nearby_gaussians(self, distance_threshold: float = 0.01) -> None:
         """Greedy merge of pairs closer than the threshold (:478-528): pairs (i < j) in row-major order, a Gaussian
         takes part in at most one merge as the removed one, the survivor gets the opacity-weighted mean of position
-        and colour (of the CURRENT values, as in the reference) and the larger opacity.  The reference materialises
-        the N x N distance matrix; here it is scanned in row blocks, so N is bounded by time, not memory."""
+        and colour (of the CURRENT values, as in the reference) and the larger opacity.
+        The reference materialises the N x N matrix of torch.cdist (4 TB at 1 M Gaussians).  On the GPU the pairs come
+        from a spatial hash (csrc/gsx_merge.hip: O(N) memory, direct fp32 distances), the order-dependent walk runs on
+        the host inside the library and the survivors are compacted on the GPU.  CPU tensors (host-side tooling) scan
+        the same matrix in row blocks with torch.cdist itself."""
+        if self.positions.is_cuda:
+            return self._merge_nearby_hip(float(distance_threshold))
         n = self.num_gaussians
         pos0 = self.positions.data
         pairs = []
@@ -205,6 +210,69 @@ class GaussianSplat(nn.Module):
             keep = torch.ones(n, dtype=torch.bool, device=pos0.device)
             keep[list(merged)] = False
             self._replace_parameters([p.data[keep] for p in (self.positions, self.scales, self.rotations, self.opacity, self.features)])
+
+    def _merge_pairs_hip(self, threshold: float):
+        """(offsets (N+1,) int64 host, partners (P,) int32 host): i's partners j > i, ascending, for every i."""
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        n = self.num_gaussians; dev = self.positions.device
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        pos = self.positions.data.contiguous().float()
+        counts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
+        wsb = lib.gsx_merge_workspace_bytes(n); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        swb = lib.gsx_scan_workspace_bytes(max(n, 1)); sws = torch.empty(swb, dtype=torch.uint8, device=dev)
+        with L.on_device(dev):
+            st = L.stream_ptr(dev)
+            L.check(lib.gsx_merge_count(ptr(pos), n, threshold, ptr(counts), ptr(ws), wsb, st), "gsx_merge_count")
+            L.check(lib.gsx_scan_u32(ptr(counts), ptr(offsets), ptr(total), n, ptr(sws), swb, st), "gsx_scan_u32")
+            n_pairs = int(total[0].item())
+            if n_pairs >= 1 << 31:
+                raise ValueError(f"merge_nearby_gaussians: {n_pairs} pairs closer than {threshold}; lower the threshold")
+            partners = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
+            if n_pairs:
+                L.check(lib.gsx_merge_fill(ptr(pos), n, threshold, ptr(offsets), ptr(partners), ptr(ws), wsb, st), "gsx_merge_fill")
+            off_host = torch.empty(n + 1, dtype=torch.int32)
+            off_host[:n] = offsets[:n].cpu(); off_host[n] = n_pairs
+            return off_host, partners[:n_pairs].cpu()
+
+    def _merge_nearby_hip(self, threshold: float) -> None:
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        n = self.num_gaussians; dev = self.positions.device
+        if n == 0 or not threshold > 0 or threshold == float("inf"):     # no d satisfies 0 < d < threshold (or the N^2 pairs of inf: refuse)
+            if threshold == float("inf"):
+                raise ValueError("merge_nearby_gaussians: an infinite threshold pairs every two Gaussians")
+            return
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        off_host, partners_host = self._merge_pairs_hip(threshold)
+        if partners_host.numel() == 0:
+            return
+        pos_h = self.positions.data.float().cpu().contiguous()
+        fea_h = self.features.data.float().cpu().contiguous()
+        opa_h = self.opacity.data.float().cpu().contiguous()
+        removed = torch.empty(n, dtype=torch.uint8)
+        L.check(lib.gsx_merge_greedy_host(n, ptr(off_host), ptr(partners_host), ptr(pos_h), ptr(fea_h), ptr(opa_h), ptr(removed)),
+                "gsx_merge_greedy_host")
+        keep = (removed == 0).to(torch.int32).to(dev)
+        srcs = [pos_h.to(dev), self.scales.data.contiguous().float(), self.rotations.data.contiguous().float(), opa_h.to(dev), fea_h.to(dev)]
+        offsets = torch.empty(n, dtype=torch.int32, device=dev)
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
+        swb = lib.gsx_scan_workspace_bytes(n); sws = torch.empty(swb, dtype=torch.uint8, device=dev)
+        out = []
+        with L.on_device(dev):
+            st = L.stream_ptr(dev)
+            L.check(lib.gsx_scan_u32(ptr(keep), ptr(offsets), ptr(total), n, ptr(sws), swb, st), "gsx_scan_u32")
+            kept = int(total[0].item())
+            for src in srcs:
+                dst = torch.empty((kept,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+                if kept:
+                    L.check(lib.gsx_compact_rows(ptr(src), ptr(keep), ptr(offsets), n, src.numel() // n, ptr(dst), st), "gsx_compact_rows")
+                out.append(dst)
+        self._replace_parameters(out)
 
     def last_n_composited(self):
         """Number of Gaussians composited before the global early exit (:147) in the last

@@ -36,7 +36,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 14
+#define GSX_ABI_VERSION 15
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -277,6 +277,24 @@ int gsx_keep_flags(const float* opacity, int32_t N, float threshold, uint32_t* k
 int gsx_compact_rows(const float* src, const uint32_t* keep, const uint32_t* offsets, int32_t N, int32_t row_floats,
                      float* dst, void* stream);
 int gsx_clamp_inplace(float* x, int64_t n, float lo, float hi, void* stream);
+
+/* merge_nearby_gaussians (model/gaussian_splatting.py:477-528) without the N x N matrix of torch.cdist (:491).
+ * gsx_merge_count hashes the positions (N x 3, device) into a grid of cells just wider than the threshold, sorts the
+ * points by bucket and writes counts[i] = number of partners j > i with 0 < |p_i - p_j| < threshold (:494-497: the
+ * upper triangle); the caller scans the counts (gsx_scan_u32; the total is the number of pairs) and gsx_merge_fill, given
+ * the SAME ws untouched, writes i's partners at partners[offsets[i] ..], ascending -- together the pairs in the
+ * reference's row-major order.  Distances are sqrt((dx*dx + dy*dy) + dz*dz) in fp32; torch.cdist's matmul form rounds
+ * differently by ~1e-4 relative, so pairs that close to the threshold (or to zero) may be decided differently.
+ * gsx_merge_greedy_host is the order-dependent walk over those pairs (:500-515) on HOST copies: skips a pair when
+ * either end is already removed, otherwise writes the opacity-weighted mean of the current positions / colours and the
+ * larger opacity into i and sets removed[j]; the caller compacts with gsx_compact_rows (:518-528).  It accepts j == i
+ * (the reference's list holds such pairs where cdist rounds a self-distance above zero; gsx_merge_fill never emits one). */
+size_t gsx_merge_workspace_bytes(int32_t N);
+int gsx_merge_count(const float* positions, int32_t N, float threshold, uint32_t* counts, void* ws, size_t ws_bytes, void* stream);
+int gsx_merge_fill(const float* positions, int32_t N, float threshold, const uint32_t* offsets, uint32_t* partners,
+                   const void* ws, size_t ws_bytes, void* stream);
+int gsx_merge_greedy_host(int32_t N, const uint32_t* offsets_host, const uint32_t* partners_host,
+                          float* positions_host, float* features_host, float* opacity_host, uint8_t* removed_host);
 
 #ifdef __cplusplus
 }

@@ -267,7 +267,38 @@ EXIT_CASES = [
 ]
 
 
+def run_merge_case(name, n, seed, threshold):
+    """merge_nearby_gaussians (:477-528) on a default-init scene.  Besides inputs and outputs the fixture keeps the
+    reference's own pair list (the expressions of :491-497): above 25 rows torch.cdist takes its matmul form, whose
+    self-distances round above zero for about a tenth of the points -- the reference then "merges" such a point with
+    itself and removes it.  `self_pairs` counts them; `margin` is how far (float64) the nearest off-diagonal distance
+    stays from the threshold, so a test can tell a real disagreement from that rounding."""
+    torch.manual_seed(seed)
+    model = GaussianSplat(n)
+    before = {k: getattr(model, k).data.clone().numpy() for k in ("positions", "scales", "rotations", "opacity", "features")}
+    d = torch.cdist(model.positions.data, model.positions.data)
+    ii, jj = torch.where(torch.triu(d > 0) & torch.triu(d < threshold))
+    d64 = torch.cdist(model.positions.data.double(), model.positions.data.double())
+    off = ~torch.eye(n, dtype=torch.bool)
+    margin = float((d64[off] - threshold).abs().min())
+    model.merge_nearby_gaussians(threshold)
+    out = {"threshold": np.float32(threshold), "pairs_i": ii.numpy().astype(np.int32), "pairs_j": jj.numpy().astype(np.int32),
+           "self_pairs": np.int32(int((ii == jj).sum())), "margin": np.float64(margin), "n_after": np.int32(model.num_gaussians)}
+    for k, v in before.items():
+        out["in_" + k] = v
+        out["out_" + k] = getattr(model, k).data.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: {n} -> {model.num_gaussians}, {len(ii)} pairs ({int((ii == jj).sum())} self), margin {margin:.2e}")
+
+
+MERGE_CASES = [("merge_n24", 24, 1, 0.3), ("merge_n300", 300, 2, 0.1), ("merge_n1500", 1500, 4, 0.03)]
+
+
 def main():
+    if "--merge-only" in sys.argv:
+        for c in MERGE_CASES:
+            run_merge_case(*c)
+        return
     if "--exit-only" in sys.argv:
         for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
             run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
@@ -294,6 +325,8 @@ def main():
     run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
     for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
         run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
+    for c in MERGE_CASES:
+        run_merge_case(*c)
     if big:
         # BASELINE config 1: 5000 default-init Gaussians, 400x300 (README.md:85-94); ~16 GB RSS, ~10 s
         run_case("config1_5000_400x300", scene_default(5000, 0), I3, 300, 400, 0,
