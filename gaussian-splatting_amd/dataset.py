@@ -1,115 +1,120 @@
-"""the step in front of the render path in training -- the reference's on-disk scene format
-(/root/reference/data_processing/dataset.py:11-216, written by data_processing/preprocessor.py:177-220,262-293):
+"""the step in front of the render path in training -- a reader for the reference's on-disk scene
+format (what /root/reference/data_processing/preprocessor.py:177-220,262-293 writes and
+data_processing/dataset.py:11-216 reads):
 
-    <root>/images/<split>/*.jpg          sorted by name
-    <root>/poses/<split>_poses.npy       (n, 4, 4)
+    <root>/images/<split>/*.jpg          one view per file, name order = pose order
+    <root>/poses/<split>_poses.npy       (n, 4, 4) world->camera
     <root>/metadata/scene_info.json
 
-`SceneDataset` mirrors the reference class (same constructor, items, errors, helper methods).  The reference
-decodes with OpenCV, which this image does not have; PIL decodes the same JPEG bytes, and the optional resize uses
-PIL's BOX filter where the reference uses cv2.INTER_AREA (both area averages; not bit-identical -- "parity
-unpinned" for the resize, no fixture of the reference covers it).  `DevicePrefetcher` is the MI355X side: items are
-staged in pinned host memory and copied to the GPU on a side stream one step ahead, so the trainer's stream never
-waits on PCIe."""
+The interface kept from the reference is what its trainer consumes: `SceneDataset(root, split, transform, image_size)`,
+`len()`, and items `{'image': (3,H,W) float32 in [0,1], 'camera_pose': (4,4) float32, 'image_path': str}`, with the
+same exception types for a bad split, missing files and an image/pose count mismatch.  Everything else is this
+package's own: the scene is resolved once into a `SceneFiles` record, views can be fetched as raw uint8 (`view_u8`) so
+that the prefetcher moves one byte per channel over PCIe and scales on the GPU, and the metadata is exposed as the
+parsed JSON (`info`) rather than through helper methods.
+The reference decodes with OpenCV, which this image does not have; PIL decodes the same JPEG bytes, and the optional
+resize uses PIL's BOX filter where the reference uses cv2.INTER_AREA (both area averages; not bit-identical -- "parity
+unpinned" for the resize, no fixture of the reference covers it)."""
 import json
-import logging
-from pathlib import Path
+import os
+from typing import NamedTuple
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+SPLITS = ('train', 'val', 'test')
+
+
+class SceneFiles(NamedTuple):
+    views: tuple              # image file paths, name order
+    poses: np.ndarray         # (n, 4, 4) float32
+    info: dict                # metadata/scene_info.json, parsed
+
+
+def resolve_scene(root, split) -> SceneFiles:
+    """Checks the three parts of a split and loads the small ones (poses, metadata)."""
+    if split not in SPLITS:
+        raise ValueError(f"unknown split {split!r}: a scene has {', '.join(SPLITS)}")
+    root = os.fspath(root)
+    parts = {'info': os.path.join(root, 'metadata', 'scene_info.json'),
+             'views': os.path.join(root, 'images', split),
+             'poses': os.path.join(root, 'poses', split + '_poses.npy')}
+    for what, path in parts.items():
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"scene {root!r}, split {split!r}: no {what} at {path}")
+    with open(parts['info']) as f:
+        info = json.load(f)
+    views = tuple(sorted(os.path.join(parts['views'], name) for name in os.listdir(parts['views']) if name.endswith('.jpg')))
+    poses = np.load(parts['poses'], allow_pickle=False)
+    if poses.ndim != 3 or poses.shape[1:] != (4, 4) or poses.shape[0] != len(views):
+        raise ValueError(f"scene {root!r}, split {split!r}: {len(views)} views but poses of shape {poses.shape}")
+    return SceneFiles(views, np.ascontiguousarray(poses, dtype=np.float32), info)
+
 
 class SceneDataset(Dataset):
     def __init__(self, data_path, split='train', transform=None, image_size=None):
-        self.data_path = Path(data_path)
-        if split not in ['train', 'val', 'test']:
-            raise ValueError(f"Split must be one of ['train', 'val', 'test'], got {split}")
-        self.split = split
-        self.transform = transform
-        self.image_size = image_size
-        self.logger = logging.getLogger(__name__)
-        self.scene_info = self._load_scene_info()
-        self.image_paths = self._get_image_paths()
-        self.camera_poses = self._load_camera_poses()
-        if len(self.image_paths) != len(self.camera_poses):
-            raise ValueError(f"Number of images ({len(self.image_paths)}) does not match "
-                             f"number of camera poses ({len(self.camera_poses)})")
+        self.files = resolve_scene(data_path, split)
+        self.split, self.transform = split, transform
+        self.image_size = None if image_size is None else (int(image_size[0]), int(image_size[1]))     # (W, H), as for cv2.resize
+
+    info = property(lambda self: self.files.info)
 
     def __len__(self):
-        return len(self.image_paths)
+        return len(self.files.views)
+
+    def view_u8(self, idx) -> np.ndarray:
+        """View idx as (H, W, 3) uint8 RGB, resized to image_size when one was given."""
+        from PIL import Image
+        path = self.files.views[idx]
+        try:
+            with Image.open(path) as im:
+                im = im.convert('RGB')
+                if self.image_size is not None and im.size != self.image_size:
+                    im = im.resize(self.image_size, Image.BOX)
+                return np.array(im, dtype=np.uint8)
+        except (OSError, ValueError) as e:
+            raise ValueError(f"cannot decode view {idx} of split {self.split!r}: {path}") from e
+
+    def pose(self, idx) -> torch.Tensor:
+        return torch.from_numpy(self.files.poses[idx].copy())
 
     def __getitem__(self, idx):
-        image_path = self.image_paths[idx]
-        image = self._load_image(image_path)
-        image = self.transform(image) if self.transform is not None else self._default_transform(image)
-        return {'image': image, 'camera_pose': torch.from_numpy(self.camera_poses[idx]).float(), 'image_path': str(image_path)}
-
-    def _load_scene_info(self):
-        info_path = self.data_path / 'metadata' / 'scene_info.json'
-        if not info_path.exists():
-            raise FileNotFoundError(f"Scene info not found at {info_path}")
-        with open(info_path) as f:
-            return json.load(f)
-
-    def _get_image_paths(self):
-        image_dir = self.data_path / 'images' / self.split
-        if not image_dir.exists():
-            raise FileNotFoundError(f"Image directory not found at {image_dir}")
-        return sorted(image_dir.glob('*.jpg'))
-
-    def _load_camera_poses(self):
-        poses_path = self.data_path / 'poses' / f'{self.split}_poses.npy'
-        if not poses_path.exists():
-            raise FileNotFoundError(f"Camera poses not found at {poses_path}")
-        return np.load(poses_path)            # allow_pickle stays False
-
-    def _load_image(self, image_path):
-        """(H, W, 3) uint8 RGB; image_size, when given, is (W, H) as for cv2.resize (dataset.py:146)."""
-        from PIL import Image
-        try:
-            with Image.open(str(image_path)) as im:
-                im = im.convert('RGB')
-                if self.image_size is not None:
-                    im = im.resize(tuple(self.image_size), Image.BOX)
-                return np.asarray(im, dtype=np.uint8).copy()
-        except (OSError, ValueError) as e:
-            raise ValueError(f"Failed to load image: {image_path}") from e
-
-    def _default_transform(self, image):
-        return torch.from_numpy(image.astype(np.float32) / 255.0).permute(2, 0, 1)
-
-    def get_camera_intrinsics(self):
-        try:
-            camera_info = self.scene_info['metadata']['camera']
-            return {'focal_length': camera_info['focal_length'], 'principal_point': tuple(camera_info['principal_point']),
-                    'image_size': tuple(self.scene_info['processing']['image_size'])}
-        except KeyError:
-            self.logger.warning("Camera intrinsics not found in metadata")
-            H, W = self._load_image(self.image_paths[0]).shape[:2]
-            return {'focal_length': max(H, W), 'principal_point': (W / 2, H / 2), 'image_size': (W, H)}
-
-    def get_scene_bounds(self):
-        positions = self.camera_poses[:, :3, 3]
-        lo, hi = positions.min(axis=0), positions.max(axis=0)
-        return {'center': (lo + hi) / 2, 'extent': hi - lo, 'aabb': np.stack([lo, hi])}
+        rgb = self.view_u8(idx)
+        image = self.transform(rgb) if self.transform is not None else torch.from_numpy(rgb).permute(2, 0, 1).float().div_(255.0)
+        return {'image': image, 'camera_pose': self.pose(idx), 'image_path': self.files.views[idx]}
 
 
 class DevicePrefetcher:
-    """Iterates a dataset (or any iterable of SceneDataset items) and yields (image (1,3,H,W), camera_pose (1,4,4),
-    image_path) already on `device`.  Item k+1 is decoded, staged in pinned memory and copied on a side stream while
-    the caller renders item k; the caller's stream waits on the copy's event only."""
+    """Iterates a dataset (or any sequence of SceneDataset-shaped items) and yields (image (1,3,H,W), camera_pose
+    (1,4,4), image_path) already on `device`.  Item k+1 is decoded, staged in pinned memory and copied on a side stream
+    while the caller renders item k; the caller's stream waits on the copy's event only.
+    A SceneDataset without a transform is read as uint8 (`view_u8`): one byte per channel crosses PCIe and the
+    conversion to float32 in [0,1] runs on the GPU through a 256-entry table of the host's own i / 255 values, so the
+    tensor is bit-identical to the dataset's item."""
 
     def __init__(self, dataset, device, order=None):
         self.dataset, self.device = dataset, torch.device(device)
         self.order = list(range(len(dataset))) if order is None else list(order)
         self.cuda = self.device.type == 'cuda'
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.as_bytes = self.cuda and hasattr(dataset, 'view_u8') and getattr(dataset, 'transform', None) is None
+        self.unit = (torch.arange(256, dtype=torch.float32) / 255.0).to(self.device) if self.as_bytes else None
 
     def __len__(self):
         return len(self.order)
 
     def _stage(self, idx):
+        if self.as_bytes:
+            raw = torch.from_numpy(self.dataset.view_u8(idx)).pin_memory()                   # (H, W, 3) uint8
+            pose = self.dataset.pose(idx).unsqueeze(0).pin_memory()
+            path = self.dataset.files.views[idx]
+            with torch.cuda.stream(self.stream):
+                d_raw = raw.to(self.device, non_blocking=True)
+                d_img = self.unit.index_select(0, d_raw.permute(2, 0, 1).reshape(-1).int()).view(1, 3, raw.shape[0], raw.shape[1])
+                d_pose = pose.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(self.stream)
+            return d_img, d_pose, path, (ev, raw, pose)
         item = self.dataset[idx]
         img, pose = item['image'].unsqueeze(0).contiguous(), item['camera_pose'].unsqueeze(0).contiguous()
         if not self.cuda:

@@ -277,7 +277,8 @@ def _write_scene(root, n=5, H=12, W=16, split="train"):
 
 
 def test_scene_dataset_follows_reference_format(tmp_path):
-    """SURVEY 8f N2 (data_processing/dataset.py:11-216): items, dtypes, ordering, helper methods and errors."""
+    """SURVEY 8f N2 (data_processing/dataset.py:11-216): items, dtypes, ordering and error types of the reference's
+    dataset on the reference's on-disk format; the reader behind them is this package's own."""
     import torch
     from gaussian_splatting_amd.dataset import SceneDataset, DevicePrefetcher
     root = str(tmp_path / "scene")
@@ -294,9 +295,14 @@ def test_scene_dataset_follows_reference_format(tmp_path):
     assert np.abs(decoded * 255 - imgs[2]).mean() < 20                                      # and it is the image that was written (lossy JPEG)
     assert it["camera_pose"].dtype == torch.float32 and np.allclose(it["camera_pose"].numpy(), poses[2].astype(np.float32))
     assert SceneDataset(root, "train", image_size=(8, 6))[0]["image"].shape == (3, 6, 8)    # (W, H) like cv2.resize
-    assert ds.get_camera_intrinsics() == {"focal_length": 20.0, "principal_point": (8.0, 6.0), "image_size": (16, 12)}
-    b = ds.get_scene_bounds()
-    assert np.allclose(b["aabb"], np.stack([poses[:, :3, 3].min(0), poses[:, :3, 3].max(0)]))
+    assert ds.info["metadata"]["camera"]["focal_length"] == 20.0 and ds.info["processing"]["image_size"] == [16, 12]
+    assert ds.view_u8(2).dtype == np.uint8 and np.array_equal(ds.view_u8(2).astype(np.float32) / 255.0, decoded)
+    assert ds.files.poses.dtype == np.float32 and ds.files.poses.shape == (5, 4, 4)
+    called = []
+    tds = SceneDataset(root, "train", transform=lambda a: called.append(a.shape) or torch.zeros(1))
+    assert tds[1]["image"].shape == (1,) and called == [(12, 16, 3)]                        # the transform gets the HWC uint8 array
+    (tmp_path / "scene" / "images" / "train" / "notes.txt").write_text("not a view")        # only *.jpg files are views
+    assert len(SceneDataset(root, "train")) == 5
     with pytest.raises(ValueError):
         SceneDataset(root, "holdout")
     with pytest.raises(FileNotFoundError):
