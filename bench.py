@@ -12,9 +12,15 @@ configuration: 1M Gaussians, 1024x1024, the 60-view orbit of config 3 (SURVEY 8d
 A "step" is one trainer step on one view per GPU (trainer.py:134-175 sequence): zero_grad ->
 render forward -> L1 loss -> render backward -> [N>1: one RCCL all-reduce of the flat 14*N
 gradient buffer, or the all-to-all + all-gather mesh schedule if that timed faster at start-up] -> clip_grad_norm_(0.1) -> Adam step.
-View of rank r at step s is ((s*N + r) * 7) mod 60: views are sharded over GPUs, per-GPU work is fixed (weak scaling),
-and the stride (7 is coprime with 60) makes ANY window of steps a sample of the whole orbit -- the orbit's views differ 2x
-in instance count, so walking them in order made the value depend on which stretch `--steps` happened to time.
+N = 1: the view of step s is (s * 7) mod 60: the stride (7 is coprime with 60) makes ANY window of steps a sample of the
+whole orbit -- the orbit's views differ 2x in instance count, so walking them in order made the value depend on which
+stretch `--steps` happened to time.
+N > 1: views are sharded over GPUs, per-GPU work is fixed (weak scaling): one view per GPU per step, every view of the
+orbit once per epoch of 60/N steps.  A step ends when its slowest rank ends (the gradient exchange waits for all), so WHICH
+views share a step matters: `distributed.BalancedViewSampler` (the package's stand-in for the reference's
+DistributedSampler) groups views of similar instance count into the same step; the counts come from one untimed forward
+pass over the orbit at start-up.  `--view-order strided` gives the plain ((s*N + r) * 7) mod 60 assignment instead; the
+line reports the cost imbalance (max / mean over the ranks of a step) of both.
 value = N * K * H * W / max-over-ranks wall time / 1e6 (Mpix/s), inputs resident in HBM.
 
 Rank 0 also reports (same JSON line):
@@ -183,6 +189,9 @@ def main():
     ap.add_argument("--dp-schedule", default=None, choices=("allreduce", "mesh", "auto"),
                     help="gradient exchange: one RCCL all-reduce (default), all-to-all + local sum + all-gather (SURVEY 8e's mesh "
                          "schedule), or auto = time both on a scratch buffer at the first exchange and keep the faster")
+    ap.add_argument("--view-order", default="balanced", choices=("balanced", "strided"),
+                    help="N>1: which views share a step -- balanced = views of similar instance count (BalancedViewSampler), "
+                         "strided = ((s*N + r) * 7) mod 60")
     ap.add_argument("--verbose", action="store_true", help="phase progress lines on stderr")
     ap.add_argument("--hang-dump", type=int, default=0, metavar="SECONDS",
                     help="dump every thread's Python stack and exit if the run is still going after SECONDS")
@@ -227,7 +236,7 @@ def main():
     from gaussian_splatting_amd import GaussianSplat
     from gaussian_splatting_amd import render as R
     from gaussian_splatting_amd.scenes import config_scene, create_orbit_poses
-    from gaussian_splatting_amd.distributed import DataParallelSplat
+    from gaussian_splatting_amd.distributed import DataParallelSplat, BalancedViewSampler
     from gaussian_splatting_amd.trainer import make_optimizer, train_step, l1_loss, l1_ssim_loss
     loss_fn = l1_ssim_loss if args.loss == "l1_ssim" else l1_loss
 
@@ -251,8 +260,32 @@ def main():
     target_cpu = torch.rand(1, 3, H, W, generator=g)
     target = target_cpu.to(dev)
 
+    # ---- which view a rank renders at step s ---------------------------------------------------------------
+    balance = None
+    schedule_views = None
+    if world > 1 and args.view_order == "balanced" and not args.inference:
+        local = {}
+        with torch.no_grad():
+            for v in range(rank, N_VIEWS, world):                   # each rank counts its share of the orbit, untimed
+                model(poses[v:v + 1], (H, W))
+                local[v] = R.last_instance_count()
+        costs = BalancedViewSampler.gather_costs(local, N_VIEWS, device=dev)
+        sampler = BalancedViewSampler(N_VIEWS, world, rank, shuffle=True, seed=0, costs=costs)
+        schedule_views, need, epoch = [], args.warmup + args.steps + N_VIEWS, 0
+        while len(schedule_views) < need:
+            sampler.set_epoch(epoch); schedule_views += list(sampler); epoch += 1
+        strided = [[view_of(st, r, world) for r in range(world)] for st in range(N_VIEWS)]
+        imb = lambda groups: sum(max(costs[v] for v in g_) / (sum(costs[v] for v in g_) / len(g_)) for g_ in groups) / len(groups)
+        balance = {"sampler": "BalancedViewSampler(costs = instance counts of one untimed forward pass over the orbit)",
+                   "cost_imbalance_max_over_mean": round(sampler.imbalance(), 4), "strided_order_would_be": round(imb(strided), 4),
+                   "instances_min_max": [int(min(costs)), int(max(costs))]}
+        phase(f"view costs gathered, imbalance {balance}")
+
+    def view_for(s):
+        return schedule_views[s] if schedule_views is not None else view_of(s, rank, world)
+
     def step(s):
-        v = view_of(s, rank, world)
+        v = view_for(s)
         if args.no_optimizer:
             opt.zero_grad()
             out = net(poses[v:v + 1], (H, W))
@@ -268,7 +301,7 @@ def main():
 
     def orbit_pass(first, count):
         """forward-only: `count` views of this rank's share of the orbit in ONE render_frames call (views pipelined over streams)"""
-        idx = torch.tensor([view_of(first + i, rank, world) for i in range(count)], device=dev)
+        idx = torch.tensor([view_for(first + i) for i in range(count)], device=dev)
         model.render_frames(poses[idx], (H, W))
 
     def run(first, count):
@@ -310,7 +343,7 @@ def main():
     d_sum = 0
     k_prof = 0 if args.inference else min(args.steps, N_VIEWS)
     for s in range(k_prof):
-        v = view_of(args.warmup + s, rank, world)     # the views the timed region rendered
+        v = view_for(args.warmup + s)                 # the views the timed region rendered
         opt.zero_grad()
         out = net(poses[v:v + 1], (H, W))
         d_sum += R.last_instance_count()
@@ -352,7 +385,7 @@ def main():
 
     if rank == 0:
         value = world * args.steps * H * W / dt / 1e6
-        timed_views = [view_of(args.warmup + s, 0, world) for s in range(args.steps)]
+        timed_views = [view_for(args.warmup + s) for s in range(args.steps)]
         line = {
             "metric": ("forward-only (inference) " if args.inference else "fwd+bwd ") + "splat-render Mpixels/s "
                       + ("@1M Gaussians 1024^2" if args.config == "c3" else f"@{n} Gaussians {W}x{H} (not the headline configuration)"),
@@ -365,7 +398,10 @@ def main():
                                    + (" (INFERENCE: forward only, not the headline metric)" if args.inference else " (render fwd+bwd only)" if args.no_optimizer else (f" (fwd + {args.loss.upper()} + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
                                       else f" (fwd + {args.loss.upper()} + bwd + fused clip_grad_norm+Adam)")),
                        "views_per_step": world, "parallelism": f"dp{world} over views",
-                       "view_order": f"rank r, step s -> orbit view ((s*{world} + r) * {VIEW_STRIDE}) mod {N_VIEWS}",
+                       "view_order": ("balanced: every orbit view once per epoch, views of similar instance count share a step"
+                                      if schedule_views is not None else
+                                      f"rank r, step s -> orbit view ((s*{world} + r) * {VIEW_STRIDE}) mod {N_VIEWS}"),
+                       **({"step_balance": balance} if balance else {}),
                        "views_timed_rank0": {"count": len(timed_views), "distinct": len(set(timed_views)), "first": timed_views[:8]},
                        **({"gradient_exchange": net.schedule} if use_dp else {})},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "rccl": rccl, "stage_ms": stages,

@@ -31,6 +31,91 @@ def shard_views(n_views, rank, world):
     return list(range(rank, n_views, world))
 
 
+class BalancedViewSampler(torch.utils.data.Sampler):
+    """Stands where the reference puts `DistributedSampler(train_dataset)` (scripts/train.py:106-110): every rank draws
+    its share of the views of an epoch, all views are visited once (the list is padded by repetition to a multiple of
+    the world size, as DistributedSampler does), `set_epoch` reshuffles, `len()` is the per-rank count.
+
+    What it adds is the reason it exists: a data-parallel step ends when its SLOWEST rank ends (the gradient exchange
+    waits for all), and a view's cost is proportional to its instance count, which differs 2x between the views of
+    one orbit.  With `costs` (one number per view -- the instance counts D the render path reports,
+    `render.last_instance_count()`; any monotone proxy will do) the views are ranked by cost and each step's `world`
+    views are NEIGHBOURS in that ranking, so the ranks of a step finish together; which group comes when is shuffled
+    per epoch (or kept cost-descending with shuffle=False), and the members of a group rotate over the ranks from
+    epoch to epoch so that no rank keeps the costliest view of its groups.  Without costs the order is the plain strided
+    one (view v -> rank v mod world).  Every rank computes the same table from the same costs: no communication here
+    (`gather_costs` is the one collective, for ranks that each measured only their own views)."""
+
+    def __init__(self, data_source, num_replicas=None, rank=None, shuffle=True, seed=0, costs=None):
+        self.n = data_source if isinstance(data_source, int) else len(data_source)
+        if num_replicas is None:
+            num_replicas = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if not 0 <= rank < num_replicas:
+            raise ValueError(f"rank {rank} outside a world of {num_replicas}")
+        self.world, self.rank, self.shuffle, self.seed, self.epoch = int(num_replicas), int(rank), bool(shuffle), int(seed), 0
+        self.costs = None
+        if costs is not None:
+            self.set_costs(costs)
+
+    def set_costs(self, costs):
+        costs = [float(c) for c in costs]
+        if len(costs) != self.n:
+            raise ValueError(f"{len(costs)} costs for {self.n} views")
+        self.costs = costs
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return (self.n + self.world - 1) // self.world
+
+    def steps(self):
+        """The epoch as a list of steps, each a list of `world` view indices (entry r is rank r's view)."""
+        if self.n == 0:
+            return []
+        if self.costs is None:
+            order = list(range(self.n))
+        else:
+            order = sorted(range(self.n), key=lambda v: (-self.costs[v], v))
+        order += order[:len(self) * self.world - self.n]                 # pad by repetition
+        groups = [order[i:i + self.world] for i in range(0, len(order), self.world)]
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        if self.shuffle:
+            groups = [groups[i] for i in torch.randperm(len(groups), generator=g).tolist()]
+        if self.costs is not None:
+            groups = [grp[(k + self.epoch) % self.world:] + grp[:(k + self.epoch) % self.world] for k, grp in enumerate(groups)]
+        return groups
+
+    def __iter__(self):
+        return iter([grp[self.rank] for grp in self.steps()])
+
+    @staticmethod
+    def gather_costs(local, n_views, group=None, device=None):
+        """local: {view: cost} this rank measured.  Returns the full list (MAX over ranks per view; views nobody
+        measured get the mean of the measured ones) -- one small all-reduce."""
+        t = torch.full((n_views,), -1.0, dtype=torch.float64)
+        for v, c in local.items():
+            t[v] = float(c)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            on_dev = device is not None and dist.get_backend(group) == "nccl"
+            if on_dev:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            t = t.cpu()
+        known = t[t >= 0]
+        fill = float(known.mean()) if known.numel() else 0.0
+        return [float(c) if c >= 0 else fill for c in t.tolist()]
+
+    def imbalance(self):
+        """mean over the steps of (max cost in the step / mean cost in the step): 1.0 = the ranks finish together."""
+        if self.costs is None:
+            return None
+        r = [max(self.costs[v] for v in grp) / max(sum(self.costs[v] for v in grp) / len(grp), 1e-30) for grp in self.steps()]
+        return sum(r) / len(r) if r else 1.0
+
+
 def _flat_view_of(tensors, tail=0):
     """If the tensors are consecutive views into one contiguous storage (as RenderFunction.backward
     lays the gradients out) with at least `tail` more elements behind the last, return that flat tensor

@@ -218,6 +218,16 @@ dp.tune_schedule(14 * N + 8, torch.device("cpu"))
 picks = [None] * world; dist.all_gather_object(picks, (dp.schedule, dp.tuned_ms["mesh"]))
 assert picks == [("allreduce", None)] * world, picks
 assert (dp.tune_error is not None) == (rank == 1)
+# ---- the view sampler: each rank measured only its own views, one collective completes the table ---------------------
+from gaussian_splatting_amd.distributed import BalancedViewSampler
+true_cost = [100.0 + 50.0 * ((v * 7) % 12) for v in range(12)]
+costs = BalancedViewSampler.gather_costs({v: true_cost[v] for v in range(rank, 12, world)}, 12)
+assert costs == true_cost
+mine = list(BalancedViewSampler(12, costs=costs, seed=3))          # world and rank from the process group
+both = [None] * world; dist.all_gather_object(both, mine)
+assert sorted(both[0] + both[1]) == list(range(12))                # disjoint, covering
+for a_, b_ in zip(both[0], both[1]):                               # the two views of a step are neighbours in cost
+    assert abs(true_cost[a_] - true_cost[b_]) <= 50.0
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -280,3 +290,38 @@ def test_launches_follow_the_tensors_device(monkeypatch):
         with L.on_device(torch.device("cuda", 2)):
             raise ValueError("restored on the way out too")
     assert state["cur"] == 0
+
+
+def test_balanced_view_sampler():
+    """The stand-in for the reference's DistributedSampler (scripts/train.py:106-110): per-rank shares that cover the
+    views once per epoch, identical tables on every rank, views of similar cost in the same step."""
+    import math
+    from gaussian_splatting_amd.distributed import BalancedViewSampler as S
+    from torch.utils.data.distributed import DistributedSampler
+    n = 60
+    costs = [2.0 + math.cos(2 * math.pi * v / 30) + 0.3 * math.sin(v) for v in range(n)]      # an orbit's 2x swing
+    for world in (1, 2, 4, 8):
+        shares = [list(S(n, world, r, costs=costs, seed=1)) for r in range(world)]
+        per_rank = (n + world - 1) // world
+        assert all(len(sh) == per_rank == len(S(n, world, 0)) for sh in shares)
+        seen = sorted(v for sh in shares for v in sh)
+        assert set(seen) == set(range(n)) and len(seen) == per_rank * world             # padded by repetition only
+        tables = [S(n, world, r, costs=costs, seed=1).steps() for r in range(world)]
+        assert all(t == tables[0] for t in tables)                                      # no communication needed
+        assert [[t[r] for t in tables[0]] for r in range(world)] == shares
+        bal = S(n, world, 0, costs=costs).imbalance()
+        strided = [[((s * world + r) * 7) % n for r in range(world)] for s in range(n)]
+        plain = sum(max(costs[v] for v in g) / (sum(costs[v] for v in g) / len(g)) for g in strided) / len(strided)
+        assert bal <= plain + 1e-12 and (world == 1 or bal < 1.0 + 0.4 * (plain - 1.0)), (world, bal, plain)
+    a = S(n, 4, 1, costs=costs, seed=1); e0 = list(a); a.set_epoch(1); e1 = list(a)
+    assert e0 != e1 and sorted(e0) != sorted(e1)                        # groups reshuffled, members rotate over the ranks
+    b = S(n, 4, 1, costs=costs, shuffle=False)
+    assert [costs[v] for v in b] == sorted((costs[v] for v in b), reverse=True)         # cost-descending when not shuffled
+    # without costs: DistributedSampler's unshuffled assignment (view v -> rank v mod world)
+    for r in range(4):
+        assert list(S(n, 4, r, shuffle=False)) == list(DistributedSampler(range(n), num_replicas=4, rank=r, shuffle=False))
+    with pytest.raises(ValueError):
+        S(n, 4, 4)
+    with pytest.raises(ValueError):
+        S(n, 4, 0, costs=[1.0] * 3)
+    assert list(S(0, 2, 0)) == []
