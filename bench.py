@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="phase progress lines on stderr")
     ap.add_argument("--hang-dump", type=int, default=0, metavar="SECONDS",
                     help="dump every thread's Python stack and exit if the run is still going after SECONDS")
+    ap.add_argument("--no-fused-step", action="store_true",
+                    help="keep the trainer step on the modular path (module forward, autograd, optimizer.step()) instead of the "
+                         "one-call gsx_train_step that train_step() uses for the plain single-GPU case; same kernels, same bits")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
@@ -239,6 +242,9 @@ def main():
     from gaussian_splatting_amd.distributed import DataParallelSplat, BalancedViewSampler
     from gaussian_splatting_amd.trainer import make_optimizer, train_step, l1_loss, l1_ssim_loss
     loss_fn = l1_ssim_loss if args.loss == "l1_ssim" else l1_loss
+    if args.no_fused_step:
+        import gaussian_splatting_amd.trainer as _trainer
+        _trainer.FUSED_STEP = False
 
     params, H, W = config_scene(args.config)
     n = params["positions"].shape[0]
@@ -398,6 +404,8 @@ def main():
                                    + (" (INFERENCE: forward only, not the headline metric)" if args.inference else " (render fwd+bwd only)" if args.no_optimizer else (f" (fwd + {args.loss.upper()} + bwd + torch clip_grad_norm_ + torch Adam)" if args.torch_optimizer
                                       else f" (fwd + {args.loss.upper()} + bwd + fused clip_grad_norm+Adam)")),
                        "views_per_step": world, "parallelism": f"dp{world} over views",
+                       "step_driver": ("gsx_train_step (one library call per step)" if getattr(opt, "_fused_step", None) is not None
+                                       else "module forward + autograd backward + optimizer.step()"),
                        "view_order": ("balanced: every orbit view once per epoch, views of similar instance count share a step"
                                       if schedule_views is not None else
                                       f"rank r, step s -> orbit view ((s*{world} + r) * {VIEW_STRIDE}) mod {N_VIEWS}"),

@@ -20,11 +20,11 @@ SYMBOLS = [
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd", "gsx_image_loss_fwd_grad",
     "gsx_l1_ssim_workspace_bytes", "gsx_l1_ssim_fwd", "gsx_l1_ssim_bwd",
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
-    "gsx_merge_workspace_bytes", "gsx_merge_count", "gsx_merge_fill", "gsx_merge_greedy_host",
+    "gsx_merge_workspace_bytes", "gsx_merge_count", "gsx_merge_fill", "gsx_merge_greedy_host", "gsx_train_step",
 ]
 
-ABI_VERSION = 15            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
-GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE = 0, -1, -2, -3, -4
+ABI_VERSION = 16            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE, GSX_E_AGAIN = 0, -1, -2, -3, -4, -5
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
 TILE = 16
@@ -49,6 +49,18 @@ class GsxError(RuntimeError):
 
 _lib = None
 _p, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+
+
+class GsxStep(C.Structure):
+    """struct gsx_step of include/gsx.h (gsx_train_step); tests check the size against the header's field list"""
+    _fields_ = [("param", _p * 5), ("grad", _p * 5), ("exp_avg", _p * 5), ("exp_avg_sq", _p * 5), ("lr", C.c_float * 5),
+                ("adam_order", _i32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_grad_norm", C.c_float),
+                ("step", _i64), ("write_clipped_grad", _i32), ("N", _i32), ("H", _i32), ("W", _i32), ("depth_bits", _i32),
+                ("chunk_force", _i32), ("loss_kind", _i32), ("lambda_dssim", C.c_float), ("capacity", _i64),
+                ("pose", _p), ("target", _p), ("arena", _p), ("arena_bytes", _i64),
+                ("mean2d", _p), ("depth", _p), ("cov2d", _p), ("rgb", _p), ("alpha", _p), ("state", _p), ("d_rgb", _p), ("loss", _p),
+                ("loss_ws", _p), ("loss_ws_bytes", _sz), ("adam_ws", _p), ("adam_ws_bytes", _sz),
+                ("counts_pinned_host", _p), ("count_event", _p)]
 
 
 def lib():
@@ -93,6 +105,7 @@ def lib():
     L.gsx_merge_count.argtypes = [_p, _i32, C.c_float, _p, _p, C.c_size_t, _p]
     L.gsx_merge_fill.argtypes = [_p, _i32, C.c_float, _p, _p, _p, C.c_size_t, _p]
     L.gsx_merge_greedy_host.argtypes = [_i32, _p, _p, _p, _p, _p, _p]
+    L.gsx_train_step.argtypes = [C.POINTER(GsxStep), _p]
     L.gsx_image_loss_workspace_bytes.restype = _sz
     L.gsx_image_loss_fwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _sz, _p]
     L.gsx_image_loss_bwd.argtypes = [_i32, _p, _p, _i64, _p, _p, _p]

@@ -133,3 +133,65 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, state,
                              rgb, alpha, depth_map, stream);
 }
+
+// One trainer step of one view: the view's forward above, the criterion, the two backward stages and the fused
+// clip + Adam, enqueued back to back.  The one place the host looks at the GPU is the count event, between the criterion
+// and the backward: the GPU is busy with the forward's second half meanwhile, and a step whose buffers were too small (or
+// whose depth sort was too narrow) reaches neither the backward nor the parameters.
+GSX_API int gsx_train_step(const gsx_step* s, void* stream)
+{
+    if (!s || !s->pose || !s->target || !s->d_rgb || !s->loss || !s->loss_ws || !s->counts_pinned_host || !s->count_event) return GSX_E_INVALID;
+    if (s->step < 1 || s->loss_kind < GSX_LOSS_L1 || s->loss_kind > GSX_LOSS_L1_SSIM) return GSX_E_INVALID;
+    uint32_t seen = 0;
+    for (int k = 0; k < 5; k++) {
+        if (!s->param[k] || !s->grad[k] || !s->exp_avg[k] || !s->exp_avg_sq[k]) return GSX_E_INVALID;
+        if (s->adam_order[k] < 0 || s->adam_order[k] > 4) return GSX_E_INVALID;
+        seen |= 1u << s->adam_order[k];
+    }
+    if (seen != 31u) return GSX_E_INVALID;
+    Layout L;
+    int st = make_layout(s->N, s->H, s->W, s->capacity, s->chunk_force, 1, L);
+    if (st != GSX_OK) return st;
+    st = gsx_view_forward(s->param[0], s->param[1], s->param[2], s->param[3], s->param[4], s->pose, s->N, s->H, s->W, s->capacity,
+                          s->depth_bits, nullptr, 1, s->chunk_force, s->arena, s->arena_bytes, s->mean2d, s->depth, s->cov2d,
+                          s->rgb, s->alpha, nullptr, s->state, s->counts_pinned_host, s->count_event, stream);
+    if (st != GSX_OK) return st;
+    const int64_t px = 3ll * s->H * s->W;
+    if (s->loss_kind == GSX_LOSS_L1_SSIM) {
+        st = gsx_l1_ssim_fwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, s->loss, s->loss_ws, s->loss_ws_bytes, stream);
+        if (st != GSX_OK) return st;
+        st = gsx_l1_ssim_bwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, nullptr, s->loss_ws, s->loss_ws_bytes, s->d_rgb, stream);
+    } else {
+        st = gsx_image_loss_fwd_grad(s->loss_kind, s->rgb, s->target, px, s->loss, s->d_rgb, s->loss_ws, s->loss_ws_bytes, stream);
+    }
+    if (st != GSX_OK) return st;
+    // The verdict on this step's optimism, BEFORE the backward is enqueued: a forward whose buffers were too small is
+    // truncated but in bounds, while the backward would follow offsets[] (which count every instance) past the end of the
+    // partial rows.  The GPU is still binning and compositing the view when the host gets here, so the wait is short or none.
+    GSX_HIP(hipEventSynchronize(static_cast<hipEvent_t>(s->count_event)));
+    const int64_t D = s->counts_pinned_host[0], mismatch = s->counts_pinned_host[1];
+    if (D >= 0xFFFFFFFFll) return GSX_E_RANGE;
+    if (D > s->capacity) return GSX_E_CAPACITY;
+    if (s->depth_bits < 32 && mismatch != 0) return GSX_E_AGAIN;
+    char* arena = static_cast<char*>(s->arena);
+    auto u32 = [&](int slot) { return reinterpret_cast<const uint32_t*>(arena + L.off[slot]); };
+    const float* rec = reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_REC]);
+    float* partials = reinterpret_cast<float*>(arena + L.off[GSX_VIEW_PARTIALS]);
+    st = gsx_composite_bwd(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), u32(GSX_VIEW_OFFSETS),
+                           s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,
+                           s->d_rgb, partials, stream);
+    if (st != GSX_OK) return st;
+    st = gsx_preprocess_bwd(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
+                            u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, nullptr, nullptr, nullptr, s->N, 0,
+                            s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4], stream);
+    if (st != GSX_OK) return st;
+    float* p[5]; float* g[5]; float* m[5]; float* v[5]; int64_t numel[5]; float lr[5];
+    static const int64_t per_row[5] = {3, 3, 4, 1, 3};
+    for (int k = 0; k < 5; k++) {
+        const int t = s->adam_order[k];
+        p[k] = s->param[t]; g[k] = s->grad[t]; m[k] = s->exp_avg[t]; v[k] = s->exp_avg_sq[t]; lr[k] = s->lr[t];
+        numel[k] = per_row[t] * s->N;
+    }
+    return gsx_clip_adam_step(5, p, g, m, v, numel, lr, s->beta1, s->beta2, s->eps, s->step, s->max_grad_norm, s->write_clipped_grad,
+                              s->adam_ws, s->adam_ws_bytes, stream);
+}

@@ -3,6 +3,9 @@
 clip_grad_norm_, Adam step -- with the reference's five per-tensor learning rates (:49-61).
 The reference's own loss needs VGG16/LPIPS weights from the network (model/loss.py:34,39) and
 is out of scope; the loss is a callable here."""
+import ctypes as C
+import os
+
 import torch
 
 # configs/default_config.yaml:12-16
@@ -53,6 +56,15 @@ def l1_ssim_loss(outputs, target, lambda_dssim=0.2):
     raise RuntimeError("l1_ssim_loss runs on an MI355X only (no CPU fallback)")
 
 
+def clamped_mse_loss(outputs, target):
+    """The RGB term of the reference's criterion alone (model/loss.py:135-137): mse(clamp(C, 1e-8, 1 - 1e-8), target)."""
+    c = outputs['rendered_images']
+    if c.is_cuda:
+        from . import loss as _loss
+        return _loss.clamped_mse(c, target)
+    return ((c.clamp(1e-8, 1 - 1e-8) - target) ** 2).mean()
+
+
 def reference_regularised_mse(outputs, target, w_scale=5e-4, w_opacity=5e-3):
     """The importable-math subset of model/loss.py:89-109: clamped MSE + scale and opacity
     regularisers (exercises all three gradient routes into the render backward)."""
@@ -76,9 +88,175 @@ def _unit_gradient(loss):
     return unit_gradient(loss)
 
 
+# GSX_FUSED_STEP=0 (or trainer.FUSED_STEP = False) keeps train_step on the modular path (module forward, autograd, optimizer)
+FUSED_STEP = os.environ.get("GSX_FUSED_STEP", "1") != "0"
+_FUSED_LOSSES = {}            # loss callable -> (GSX_LOSS_* kind, lambda_dssim); filled below
+
+
+class FusedTrainStep:
+    """train_step's plain case -- one view, a bare GaussianSplat on the GPU, one of this package's fused image losses,
+    FusedClipAdam -- as ONE library call (gsx_train_step): the same kernels in the same order as the module forward,
+    the loss, autograd's backward and optimizer.step(), hence the same bits, without the ~0.3 ms of interpreter,
+    autograd-engine and allocator time per step that bound a small scene (BASELINE config 2).  Everything a step needs
+    lives in buffers this object keeps; `.grad` of the five parameters are views of one flat buffer, as after the
+    modular backward; the optimizer's state (exp_avg, exp_avg_sq, step counts) is the FusedClipAdam's own, so
+    checkpoints and a later optimizer.step() see nothing unusual.  train_step() routes here by itself."""
+
+    def __init__(self, model, optimizer, kind, lambda_dssim):
+        from . import _lib as L, render as R
+        self.L, self.R = L, R
+        self.model, self.optimizer, self.kind = model, optimizer, kind
+        self.params = [model.positions, model.scales, model.rotations, model.opacity, model.features]
+        n = self.n = self.params[0].shape[0]
+        dev = self.dev = self.params[0].device
+        f32 = torch.float32
+        flat = self.flat = torch.empty(14 * n + R.GRAD_TAIL, dtype=f32, device=dev)           # RenderFunction.backward's layout
+        self.grads = [flat[4 * n:7 * n].view(n, 3), flat[7 * n:10 * n].view(n, 3), flat[0:4 * n].view(n, 4),
+                      flat[10 * n:11 * n].view(n, 1), flat[11 * n:14 * n].view(n, 3)]
+        S = self.S = L.GsxStep()
+        group_of = {}
+        for k, group in enumerate(optimizer.param_groups):
+            for p in group['params']:
+                group_of[id(p)] = k
+        order = sorted(range(5), key=lambda t: group_of[id(self.params[t])])                # the order optimizer.step() walks them in
+        for k in range(5):
+            S.param[k] = self.params[k].data_ptr(); S.grad[k] = self.grads[k].data_ptr(); S.adam_order[k] = order[k]
+        S.beta1, S.beta2 = optimizer.param_groups[0]['betas']
+        S.eps = optimizer.param_groups[0]['eps']
+        S.max_grad_norm = optimizer.max_grad_norm
+        S.write_clipped_grad = 1 if optimizer.write_clipped_grad else 0
+        S.N = n
+        S.loss_kind, S.lambda_dssim = kind, lambda_dssim
+        self.group_of = group_of
+        self.shape = None
+        self.cap = -1
+
+    def _bind_image(self, H, W):
+        L, S, dev, n = self.L, self.S, self.dev, self.n
+        f32 = torch.float32
+        self.shape = (H, W)
+        self.mean2d = torch.empty(n, 2, dtype=f32, device=dev); self.depth = torch.empty(n, dtype=f32, device=dev)
+        self.cov2d = torch.empty(n, 2, 2, dtype=f32, device=dev)
+        self.rgb = torch.empty(3, H, W, dtype=f32, device=dev); self.alpha = torch.empty(1, H, W, dtype=f32, device=dev)
+        self.d_rgb = torch.empty(3, H, W, dtype=f32, device=dev)
+        self.state = torch.empty(4, dtype=torch.int32, device=dev)
+        lib = L.lib()
+        wsb = lib.gsx_l1_ssim_workspace_bytes(3, H, W) if self.kind == 2 else lib.gsx_image_loss_workspace_bytes()
+        self.loss_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        S.H, S.W = H, W
+        S.mean2d, S.depth, S.cov2d = self.mean2d.data_ptr(), self.depth.data_ptr(), self.cov2d.data_ptr()
+        S.rgb, S.alpha, S.d_rgb, S.state = self.rgb.data_ptr(), self.alpha.data_ptr(), self.d_rgb.data_ptr(), self.state.data_ptr()
+        S.loss_ws, S.loss_ws_bytes = self.loss_ws.data_ptr(), wsb
+        self.cap = -1
+
+    def _bind_capacity(self, cap):
+        R, S = self.R, self.S
+        H, W = self.shape
+        self.arena = None                                   # the old block goes back to the allocator before the new one is asked for
+        nbytes, _, _ = R._view_layout(self.n, H, W, cap, R._scratch.force_chunk, True)
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        S.arena, S.arena_bytes, S.capacity, S.chunk_force = self.arena.data_ptr(), nbytes, cap, R._scratch.force_chunk
+        self.cap = cap
+
+    @torch.no_grad()
+    def __call__(self, pose, target):
+        L, R, S, opt, dev = self.L, self.R, self.S, self.optimizer, self.dev
+        H, W = int(target.shape[-2]), int(target.shape[-1])
+        if self.shape != (H, W):
+            self._bind_image(H, W)
+        # the optimizer's own bookkeeping (FusedClipAdam.step): state on first use, one step count for all five
+        step = None
+        for k, p in enumerate(self.params):
+            st = opt.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            s_ = opt._steps.get(p)
+            if s_ is None:
+                s_ = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
+            if step is None:
+                step = s_
+            elif step != s_:
+                raise RuntimeError("FusedTrainStep: parameters are at different step counts")
+            S.exp_avg[k] = st['exp_avg'].data_ptr(); S.exp_avg_sq[k] = st['exp_avg_sq'].data_ptr()
+            S.lr[k] = float(opt.param_groups[self.group_of[id(p)]]['lr'])
+        S.step = step + 1
+        if opt._ws is None or opt._ws.device != dev:
+            opt._ws = torch.empty(L.lib().gsx_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
+        S.adam_ws, S.adam_ws_bytes = opt._ws.data_ptr(), opt._ws.numel()
+        loss = torch.empty(3, dtype=torch.float32, device=dev)           # fresh per step: the caller may keep what is returned
+        S.loss, S.pose, S.target = loss.data_ptr(), pose.data_ptr(), target.data_ptr()
+        lib = L.lib()
+        with L.on_device(dev):
+            pinned, _ev, pinned_ptr, ev_handle = R._scratch.count_slot_raw(dev)
+            S.counts_pinned_host, S.count_event = pinned_ptr, ev_handle
+            stream = L.stream_ptr(dev)
+            while True:
+                cap = R._scratch.cap(dev, self.n)
+                if cap != self.cap or S.chunk_force != R._scratch.force_chunk:
+                    self._bind_capacity(cap)
+                S.depth_bits = R._scratch.depth_bits.get(dev, 32)
+                status = lib.gsx_train_step(C.byref(S), stream)
+                if status == L.GSX_E_CAPACITY and int(pinned[0]) > cap:   # nothing was applied: grow the block, same step again
+                    R._scratch.grow(dev, int(pinned[0]))
+                    continue
+                if status == L.GSX_E_AGAIN:                              # the depth keys' top byte is no longer constant
+                    R._scratch.depth_bits[dev] = 32
+                    continue
+                L.check(status, "gsx_train_step")
+                break
+        R._scratch.depth_bits[dev] = R.DEPTH_CHECK_BIT if int(pinned[1]) == 0 else 32
+        R._last_D = int(pinned[0])
+        for p, g in zip(self.params, self.grads):
+            if p.grad is not g:
+                p.grad = g
+            opt._steps[p] = step + 1
+        torch.autograd.graph.increment_version(self.params)              # written through raw pointers: autograd must see it
+        self.model._last_state = self.state[0:1]
+        return loss[0]
+
+
+def _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_norm):
+    """The FusedTrainStep that can stand in for this call of train_step, or None.  Cheap: runs every step."""
+    spec = _FUSED_LOSSES.get(loss_fn)
+    if spec is None or not FUSED_STEP or not torch.is_grad_enabled():
+        return None
+    from .model import GaussianSplat
+    from .optim import FusedClipAdam
+    from . import render as R
+    if type(optimizer) is not FusedClipAdam or not isinstance(model, GaussianSplat) or R._timer is not None or R.STAGED:
+        return None
+    if float(optimizer.max_grad_norm) != float(max_grad_norm) or getattr(model, "render_depth_map", False):
+        return None
+    pos = model.positions
+    dev = pos.device
+    if (not pos.is_cuda or camera_poses.shape != (1, 4, 4) or camera_poses.device != dev or camera_poses.dtype != torch.float32
+            or not camera_poses.is_contiguous() or target.device != dev or target.dtype != torch.float32 or not target.is_contiguous()
+            or tuple(target.shape[:-2]) not in ((1, 3), (3,)) or pos.shape[0] == 0):
+        return None
+    params = [model.positions, model.scales, model.rotations, model.opacity, model.features]
+    for p in params:                  # hooks (a data-parallel wrapper's, a user's) only fire on the autograd path
+        if (p.dtype != torch.float32 or not p.is_contiguous() or not p.requires_grad or p.device != dev
+                or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None)):
+            return None
+    hit = getattr(optimizer, "_fused_step", None)
+    if hit is not None and hit.model is model and hit.kind == spec[0] and all(a is b for a, b in zip(hit.params, params)):
+        return hit
+    grouped = [p for g in optimizer.param_groups for p in g['params']]
+    if len(grouped) != 5 or {id(p) for p in grouped} != {id(p) for p in params}:
+        return None
+    optimizer._fused_step = hit = FusedTrainStep(model, optimizer, spec[0], spec[1])
+    return hit
+
+
 def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad_norm=0.1):
     """One step (trainer.py:134-175).  With a DataParallelSplat model the gradient all-reduce
-    fires inside backward(); clipping then sees the averaged gradients, like DDP."""
+    fires inside backward(); clipping then sees the averaged gradients, like DDP.  The plain single-view case (bare model,
+    FusedClipAdam, l1_loss / l1_ssim_loss / clamped_mse_loss) runs as one library call (FusedTrainStep): same bits."""
+    fused_step = _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_norm)
+    if fused_step is not None:
+        return fused_step(camera_poses, target)
     optimizer.zero_grad()
     outputs = model(camera_poses, target.shape[-2:])
     loss = loss_fn(outputs, target)
@@ -92,3 +270,6 @@ def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
     return loss.detach()
+
+
+_FUSED_LOSSES.update({l1_loss: (0, 0.0), clamped_mse_loss: (1, 0.0), l1_ssim_loss: (2, 0.2)})

@@ -32,11 +32,13 @@ extern "C" {
 #define GSX_E_CAPACITY (-2)    /* caller's instance buffers / workspace too small; see out parameter */
 #define GSX_E_HIP (-3)         /* a HIP runtime call failed; gsx_last_hip_error() has the code */
 #define GSX_E_RANGE (-4)       /* problem exceeds 32-bit instance indexing */
+#define GSX_E_AGAIN (-5)       /* an optimistic assumption did not hold (gsx_train_step: depth keys not constant above bit 24);
+                                  nothing was applied, call again as the entry point's comment says */
 
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 15
+#define GSX_ABI_VERSION 16
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -268,6 +270,51 @@ int gsx_l1_ssim_fwd(const float* pred, const float* target, int32_t planes, int3
                     float* loss3, void* ws, size_t ws_bytes, void* stream);
 int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int32_t H, int32_t W, float lambda_dssim,
                     const float* upstream, const void* ws, size_t ws_bytes, float* d_pred, void* stream);
+
+/* ---- one trainer step of one view in ONE call (training/trainer.py:134-175: forward, criterion, backward,
+ * clip_grad_norm_, Adam): gsx_view_forward -> image loss (+ its gradient) -> gsx_composite_bwd -> gsx_preprocess_bwd ->
+ * gsx_clip_adam_step, the same launches in the same order on `stream` as those entry points called one by one.  Host-side
+ * convenience only, for callers whose per-step host time matters: a small scene (BASELINE config 2: 0.31 ms of kernels)
+ * is otherwise bound by its ~0.4 ms of interpreter, autograd and allocator work per step.
+ * Tensors are indexed 0..4 = positions, scales, rotations, opacity, features.  adam_order[k] = which tensor
+ * gsx_clip_adam_step sees k-th (the clip norm's partial sums follow that order; the reference's optimizer groups are
+ * positions, features, scales, rotations, opacity = {0, 4, 1, 2, 3}, trainer.py:49-61).
+ * Before the backward is enqueued the call waits for count_event (recorded in the middle of the forward: the GPU is
+ * busy with the rest of the forward meanwhile) and reads the two pinned words: D > capacity returns GSX_E_CAPACITY,
+ * depth_bits < 32 with a non-zero mismatch count returns GSX_E_AGAIN (retry with depth_bits = 32) -- in both cases
+ * neither the backward nor the optimizer was enqueued: gradients, parameters and Adam state are untouched (rgb and *loss
+ * are those of the truncated / mis-sorted view); the caller grows the block / widens the sort and calls again with the
+ * same `step`.  GSX_OK: the step is enqueued whole. */
+#define GSX_LOSS_L1_SSIM 2
+typedef struct gsx_step {
+    float* param[5];               /* updated in place */
+    float* grad[5];                /* written */
+    float* exp_avg[5];
+    float* exp_avg_sq[5];
+    float lr[5];
+    int32_t adam_order[5];
+    float beta1, beta2, eps, max_grad_norm;
+    int64_t step;                  /* Adam step count AFTER this update (>= 1) */
+    int32_t write_clipped_grad;
+    int32_t N, H, W;
+    int32_t depth_bits;            /* 32, or GSX_DEPTH_CHECK_BIT after a view whose mismatch count was 0 */
+    int32_t chunk_force;
+    int32_t loss_kind;             /* GSX_LOSS_L1, GSX_LOSS_CLAMPED_MSE, GSX_LOSS_L1_SSIM */
+    float lambda_dssim;
+    int64_t capacity;
+    const float* pose;             /* 16 floats */
+    const float* target;           /* 3 x H x W */
+    void* arena; int64_t arena_bytes;      /* gsx_view_layout(N, H, W, capacity, chunk_force, need_bwd = 1) */
+    float* mean2d; float* depth; float* cov2d; float* rgb; float* alpha;
+    uint32_t* state;               /* 4 x u32, as gsx_composite_fwd */
+    float* d_rgb;                  /* 3 x H x W floats of scratch: dLoss/drgb */
+    float* loss;                   /* 3 floats: [0] the criterion; GSX_LOSS_L1_SSIM also writes [1] = L1, [2] = SSIM */
+    void* loss_ws; size_t loss_ws_bytes;   /* gsx_image_loss_workspace_bytes() or gsx_l1_ssim_workspace_bytes(3, H, W) */
+    void* adam_ws; size_t adam_ws_bytes;   /* gsx_clip_adam_workspace_bytes() */
+    int64_t* counts_pinned_host;   /* 2 x i64 of pinned host memory: D, mismatch count */
+    void* count_event;             /* hipEvent_t */
+} gsx_step;
+int gsx_train_step(const gsx_step* s, void* stream);
 
 /* ---- maintenance of the parameter buffers (model/gaussian_splatting.py:346-369, :404-418).
  * prune_gaussians = gsx_keep_flags (keep[i] = opacity[i] > threshold) -> gsx_scan_u32 (offsets, kept count) ->

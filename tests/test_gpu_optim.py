@@ -281,3 +281,90 @@ def test_device_prefetcher_feeds_the_trainer_step(tmp_path):
         assert torch.isfinite(loss)
         seen += 1
     assert seen == 4
+
+
+@pytest.mark.parametrize("loss_name", ["l1", "l1_ssim", "clamped_mse"])
+def test_fused_train_step_equals_modular_step(loss_name):
+    """gsx_train_step (one library call per step: trainer.FusedTrainStep, which train_step routes to by itself) against the
+    modular step (module forward, fused loss, autograd backward, FusedClipAdam.step): same kernels in the same order, so
+    losses, gradients, parameters and optimizer state must be EQUAL after every step -- across a capacity growth (first
+    step of a scene), the 32 -> 24-bit switch of the depth sort and a view that breaks the 24-bit assumption."""
+    from gaussian_splatting_amd import GaussianSplat, trainer as T, render as R
+    from gaussian_splatting_amd.scenes import create_orbit_poses
+    dev = torch.device("cuda:0")
+    loss_fn = {"l1": T.l1_loss, "l1_ssim": T.l1_ssim_loss, "clamped_mse": T.clamped_mse_loss}[loss_name]
+    H, W, n = 96, 128, 20000
+    poses = torch.from_numpy(create_orbit_poses(4.0, 60, 45.0)).to(dev)
+    near = poses[7:8].clone(); near[0, :3, 3] *= 0.55                   # camera at radius 2.2: depths straddle 2.0, the keys' top byte varies
+    views = [poses[0:1], poses[13:14], poses[14:15], near.contiguous(), poses[29:30], poses[30:31]]
+    target = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+    runs = {}
+    for fused in (False, True):
+        torch.manual_seed(11)
+        m = GaussianSplat(n)
+        with torch.no_grad():
+            m.scales.mul_(0.3)
+            m.positions[:, 2] = m.positions[:, 2].abs() * 0.8 + 0.2     # the Jacobian divides by WORLD z (reference quirk): keep it off 0
+        m = m.to(dev)
+        opt = T.make_optimizer(m, fused_clip_norm=0.1)
+        R._scratch.capacity[dev] = 4096; R._scratch.depth_bits.pop(dev, None)          # both start cold, with a block the first view outgrows
+        T.FUSED_STEP = fused
+        try:
+            log = []
+            for v in views:
+                loss = T.train_step(m, opt, v, target, loss_fn, 0.1)
+                log.append((loss.clone(), [p.grad.clone() for p in m.parameters()], [p.detach().clone() for p in m.parameters()],
+                            R.last_instance_count(), m.last_n_composited(), R._scratch.depth_bits.get(dev)))
+            assert (getattr(opt, "_fused_step", None) is not None) == fused
+            runs[fused] = (log, opt.state_dict())
+        finally:
+            T.FUSED_STEP = True
+    for s, (a, b) in enumerate(zip(runs[False][0], runs[True][0])):
+        assert torch.equal(a[0], b[0]), (s, float(a[0]), float(b[0]))
+        for x, y in zip(a[1], b[1]):
+            assert torch.equal(x, y), s
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y), s
+        assert a[3:] == b[3:]
+        assert torch.isfinite(a[0]) and all(torch.isfinite(x).all() for x in a[2]), s
+    bits = [e[5] for e in runs[True][0]]
+    assert bits[1] == 24 and bits[3] == 32 and bits[-1] == 24, bits     # narrowed after a quiet view, widened by the near one, narrowed again
+    assert R._scratch.cap(dev, n) > 4096 and max(e[3] for e in runs[True][0]) > 4096      # the first views outgrew the initial block
+    R._scratch.capacity.pop(dev, None)
+    sa, sb = runs[False][1], runs[True][1]
+    assert sa["param_groups"] == sb["param_groups"]
+    for k in sa["state"]:
+        for f in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(sa["state"][k][f], sb["state"][k][f]), (k, f)
+    assert float(runs[True][0][-1][0]) != float(runs[True][0][0][0])     # the losses are per step, not one buffer seen five times
+
+
+def test_fused_train_step_declines_what_it_cannot_do():
+    """Anything but the plain case stays on the modular path: a wrapped model, a torch optimizer, a custom loss, B > 1,
+    another clip norm, a depth map."""
+    from gaussian_splatting_amd import GaussianSplat, trainer as T
+    from gaussian_splatting_amd.distributed import DataParallelSplat
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = GaussianSplat(300).to(dev)
+    opt = T.make_optimizer(m, fused_clip_norm=0.1)
+    pose = torch.eye(4, device=dev)[None].contiguous(); pose[0, 2, 3] = 3.0
+    tgt = torch.rand(1, 3, 32, 48, device=dev)
+    ok = lambda **kw: T._fused_step_for(kw.get("model", m), kw.get("opt", opt), kw.get("pose", pose), kw.get("tgt", tgt),
+                                        kw.get("loss", T.l1_loss), kw.get("clip", 0.1))
+    assert ok() is not None
+    assert ok(model=DataParallelSplat(GaussianSplat(300).to(dev))) is None
+    assert ok(opt=T.make_optimizer(m)) is None
+    assert ok(loss=T.reference_regularised_mse) is None and ok(loss=lambda o, t: T.l1_loss(o, t)) is None
+    assert ok(pose=pose.repeat(2, 1, 1)) is None and ok(clip=0.5) is None and ok(tgt=tgt.cpu()) is None
+    m.render_depth_map = True
+    assert ok() is None
+    m.render_depth_map = False
+    m.scales.requires_grad_(False)
+    opt._fused_step = None
+    assert ok() is None
+    m.scales.requires_grad_(True)
+    with torch.no_grad():
+        assert ok() is None
+    loss = T.train_step(m, opt, pose, tgt, T.l1_loss, 0.1)            # and the plain case runs
+    assert torch.isfinite(loss) and m.positions.grad is not None and opt._fused_step is not None

@@ -313,3 +313,19 @@ def test_scene_dataset_follows_reference_format(tmp_path):
     np.save(str(tmp_path / "scene" / "poses" / "train_poses.npy"), poses)
     got = list(DevicePrefetcher(SceneDataset(root, "train"), "cpu", order=[3, 0]))
     assert len(got) == 2 and got[0][0].shape == (1, 3, 12, 16) and got[0][1].shape == (1, 4, 4) and got[1][2].endswith("0000.jpg")
+
+
+def test_step_struct_layout_matches_header(tmp_path):
+    """gsx_train_step takes a struct: the ctypes mirror (_lib.GsxStep) must have the header's size and field offsets."""
+    import ctypes as C, shutil, subprocess
+    from gaussian_splatting_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    names = [f[0] for f in _lib.GsxStep._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gsx.h"\nint main(void){printf("%zu", sizeof(gsx_step));'
+                   + "".join(f'printf(" %zu", offsetof(gsx_step, {n}));' for n in names) + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == [C.sizeof(_lib.GsxStep)] + [getattr(_lib.GsxStep, n).offset for n in names]
