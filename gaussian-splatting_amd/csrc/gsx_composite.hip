@@ -55,8 +55,11 @@ __device__ __forceinline__ uint32_t rank_limit_from_state(const uint32_t* state,
 // (forward and backward agree on it, so T_{k+1}/(1 - alpha_k) is always defined)
 __device__ __forceinline__ float one_minus(float al)
 {
+    // = (f == 0 ? 2^-30 : f) in ONE instruction (v_max_u32 on the bit patterns) instead of a compare and a select: +0 is the
+    // only pattern below 2^-30's that 1 - al can produce -- the next positive value is 2^-24, half an ulp of 1; negative
+    // values (al > 1) and NaN have the sign or exponent bits set and compare above -- and 1 - 1 is +0 in round-to-nearest
     const float f = 1.0f - al;
-    return f == 0.0f ? 9.313225746e-10f : f;
+    return __uint_as_float(max(__float_as_uint(f), 0x30800000u));
 }
 
 __device__ __forceinline__ void renorm(float& m, int& e)
@@ -526,6 +529,9 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l5[kCombineBatch];
         skipped = 0;
+        // lane u of every wave fetches chunk cb + u's flag word together with the states; the scan below reads it as a lane
+        // broadcast (a scalar load inside the dependent scan is one more memory latency per chunk)
+        const uint32_t meta_l = (need_bwd && (threadIdx.x & 63) < kCombineBatch) ? chunk_meta[min(cb + (threadIdx.x & 63u), c1 - 1)] : 0u;
 #pragma unroll
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = min(cb + u, c1 - 1);
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                     // enters chunk c with |T| < 2^-(GSX_CUT_LOG2 + growth bits of c) (|m| < 1 after renorm, so a test
                     // on e suffices): then |T| stays below 2^-24 throughout the chunk.  Pixels outside the image carry
                     // no gradient and count as dark
-                    const uint32_t gb = chunk_meta[c] >> GSX_META_GROWTH_SHIFT;          // bits |T| may grow inside chunk c
+                    const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)meta_l, u) >> GSX_META_GROWTH_SHIFT;          // bits |T| may grow inside chunk c
                     const bool darkp = gb < GSX_META_GROWTH_MAX && (!inside || m == 0.0f || e <= -GSX_CUT_LOG2 - (int)gb);
                     const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
                     if ((threadIdx.x & 63) == 0) {

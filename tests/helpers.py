@@ -13,7 +13,8 @@ GRAD_RTOL = 1e-3        # parameter gradients, relative to the tensor's max magn
 
 def golden_names(include_big=True):
     names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    names = [n for n in names if not n.startswith("train")]     # trainer-step fixtures have their own test (test_gpu_optim.py)
+    # trainer-step fixtures have their own test (test_gpu_optim.py), and so do those of merge_nearby_gaussians (test_merge.py)
+    names = [n for n in names if not n.startswith(("train", "merge"))]
     if not include_big:
         names = [n for n in names if not n.startswith("config1")]
     return names
