@@ -1010,6 +1010,7 @@ GSX_API const char* gsx_strerror(int status)
         case GSX_E_CAPACITY: return "instance buffers or workspace too small";
         case GSX_E_HIP: return "HIP runtime error";
         case GSX_E_RANGE: return "problem exceeds 32-bit instance indexing";
+        case GSX_E_COMM: return "RCCL is not available or one of its calls failed";
         case GSX_E_AGAIN: return "optimistic assumption did not hold: call again as documented";
         default: return "unknown status";
     }

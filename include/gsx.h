@@ -32,13 +32,14 @@ extern "C" {
 #define GSX_E_CAPACITY (-2)    /* caller's instance buffers / workspace too small; see out parameter */
 #define GSX_E_HIP (-3)         /* a HIP runtime call failed; gsx_last_hip_error() has the code */
 #define GSX_E_RANGE (-4)       /* problem exceeds 32-bit instance indexing */
+#define GSX_E_COMM (-6)        /* RCCL could not be loaded, or one of its calls failed */
 #define GSX_E_AGAIN (-5)       /* an optimistic assumption did not hold (gsx_train_step: depth keys not constant above bit 24);
                                   nothing was applied, call again as the entry point's comment says */
 
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 16
+#define GSX_ABI_VERSION 17
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -315,6 +316,24 @@ typedef struct gsx_step {
     void* count_event;             /* hipEvent_t */
 } gsx_step;
 int gsx_train_step(const gsx_step* s, void* stream);
+
+/* ---- the gradient exchange for hosts without torch.distributed: RCCL behind five calls.  Replaces what the
+ * reference gets from dist.init_process_group("nccl") + DistributedDataParallel (scripts/train.py:65-73,134-139: the
+ * gradient average after backward) and the trainer's parameter broadcast (training/trainer.py:83-87).  The Python mirror
+ * of this package uses torch.distributed instead and never calls these.  librccl is opened on first use (by soname),
+ * not linked: gsx_comm_available() says whether that worked.
+ *   gsx_comm_unique_id : rank 0 fills GSX_COMM_ID_BYTES bytes and hands them to the other ranks out of band (a file, a socket);
+ *   gsx_comm_init      : every rank, with its GPU current; collective (returns when all `world` ranks have joined);
+ *   gsx_allreduce_avg  : buf[i] = mean over the ranks of buf[i], in place, on `stream` -- one call over the flat
+ *                        14 * N gradient block is the whole exchange of a data-parallel step;
+ *   gsx_bcast          : buf on every rank = root's buf (parameters at start, trainer.py:83-87). */
+#define GSX_COMM_ID_BYTES 128
+int gsx_comm_available(void);
+int gsx_comm_unique_id(void* id_out);
+int gsx_comm_init(int32_t rank, int32_t world, const void* unique_id, void** comm_out);
+int gsx_allreduce_avg(void* comm, float* buf, int64_t n, void* stream);
+int gsx_bcast(void* comm, float* buf, int64_t n, int32_t root, void* stream);
+int gsx_comm_destroy(void* comm);
 
 /* ---- maintenance of the parameter buffers (model/gaussian_splatting.py:346-369, :404-418).
  * prune_gaussians = gsx_keep_flags (keep[i] = opacity[i] > threshold) -> gsx_scan_u32 (offsets, kept count) ->

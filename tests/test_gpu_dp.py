@@ -96,3 +96,39 @@ def test_rccl_world1_exchange_is_identity(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT, "29673"], capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rccl ok" in r.stdout
+
+
+_COMM_WORKER = r'''
+import ctypes as C, sys, torch
+sys.path.insert(0, sys.argv[1])
+from gaussian_splatting_amd import _lib as L
+lib = L.lib()
+assert lib.gsx_comm_available() == 1
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+ident = C.create_string_buffer(128)
+L.check(lib.gsx_comm_unique_id(ident), "gsx_comm_unique_id")
+assert any(ident.raw)
+comm = C.c_void_p()
+L.check(lib.gsx_comm_init(0, 1, ident, C.byref(comm)), "gsx_comm_init")
+n = 14 * 1000 + 8
+g = torch.randn(n, device=dev); want = g.clone()
+st = L.stream_ptr(dev)
+L.check(lib.gsx_allreduce_avg(comm, g.data_ptr(), n, st), "gsx_allreduce_avg")       # mean over one rank: unchanged
+L.check(lib.gsx_bcast(comm, g.data_ptr(), n, 0, st), "gsx_bcast")
+torch.cuda.synchronize()
+assert torch.equal(g, want)
+assert lib.gsx_allreduce_avg(comm, None, 5, st) == L.GSX_E_INVALID and lib.gsx_bcast(comm, g.data_ptr(), n, 3, st) == L.GSX_E_INVALID
+assert lib.gsx_comm_init(2, 2, ident, C.byref(C.c_void_p())) == L.GSX_E_INVALID
+L.check(lib.gsx_comm_destroy(comm), "gsx_comm_destroy")
+print("comm ok")
+'''
+
+
+def test_comm_entry_points_world1(tmp_path):
+    """gsx_comm_* (the exchange for hosts without torch.distributed, SURVEY 8b): RCCL opened on first use, a communicator of
+    one rank on the one GPU there is, average and broadcast in place.  Two ranks need two GPUs (RCCL refuses two ranks on one
+    device): that leg is the driver's 8-GPU node's."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(_COMM_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
