@@ -859,6 +859,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     for (uint32_t bi = nb; bi-- > 0; ) {
         const uint32_t bs = g.begin + bi * kCBatch;
         const uint32_t cnt = min((uint32_t)kCBatch, eff_end - bs);
+        uint32_t my_mask = 0u;
         if ((uint32_t)lane < cnt) {
             const uint32_t r = ranks[bs + lane];
             const float4* R = rec + (size_t)3 * r;
@@ -868,19 +869,23 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
             const float4 a = R[0], b = R[1];
-            c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
+            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE) & ~dark_mask;
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
+        // The batch's quadrant masks as four wave-uniform bit sets (bit j of qk: instance j reaches quadrant k, dark quadrants
+        // taken out): they live in scalar registers, so the loop below neither reads a mask from LDS nor waits for it before
+        // it may fetch the record, and instances that reach no live quadrant (inside the tile's box but outside the ellipse,
+        // or occluded) are never visited -- the epilogue writes their zero rows.
+        const unsigned long long q0 = __builtin_amdgcn_ballot_w64((my_mask & 1u) != 0u), q1 = __builtin_amdgcn_ballot_w64((my_mask & 2u) != 0u);
+        const unsigned long long q2 = __builtin_amdgcn_ballot_w64((my_mask & 4u) != 0u), q3 = __builtin_amdgcn_ballot_w64((my_mask & 8u) != 0u);
+        const unsigned long long live = (q0 | q1) | (q2 | q3);
         __syncthreads();
-        uint32_t slot = (out_lane + cnt * 9u) * 4u;                // walks down with j (a multiply here compiles to a quarter-rate 64-bit mad)
-        for (uint32_t j = cnt; j-- > 0; ) {
-            slot -= 36u;                                      // byte offset into s_red
+        for (unsigned long long todo = live; todo != 0ull; ) {
+            const uint32_t j = 63u - (uint32_t)__builtin_clzll(todo);       // back to front
+            todo &= ~(1ull << j);
+            const uint32_t slot = (out_lane + j * 9u) * 4u;       // byte offset into s_red
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z)) & ~dark_mask;
-            if (mk == 0u) {                                   // inside the tile's box but outside the ellipse (or occluded): a zero row
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(s_red) + slot) = 0.f;
-                continue;
-            }
+            const uint32_t mk = (uint32_t)((q0 >> j) & 1ull) | ((uint32_t)((q1 >> j) & 1ull) << 1) | ((uint32_t)((q2 >> j) & 1ull) << 2) | ((uint32_t)((q3 >> j) & 1ull) << 3);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -915,7 +920,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             const uint32_t j = idx / 9u, c = idx - j * 9u;
             const float* sp = s_red + j * 9u;
             float out;
-            if (c == 0)      out = -GSX_LN2 * (2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
+            if (!((live >> j) & 1ull)) out = 0.0f;                // never visited: nothing of it reaches a live quadrant
+            else if (c == 0) out = -GSX_LN2 * (2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
             else if (c == 1) out = -GSX_LN2 * (s_a[j].w * sp[1] + 2.0f * s_b[j].x * sp[2]);
             else if (c <= 4) out = GSX_LN2 * sp[c + 1];
             else if (c == 5) out = sp[0] / s_b[j].y;
