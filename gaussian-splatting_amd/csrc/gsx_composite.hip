@@ -374,7 +374,6 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay, const uint32_t* __restrict__ order_tab)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
-    __shared__ uint32_t s_rank[kCBatch];
     if (!PASS1 && blockIdx.x == 0) {          // the combine pass (next launch) counts in these; pass 0 itself reads neither
         if (threadIdx.x < 4) state[threadIdx.x] = 0u;
         if (threadIdx.x < 16) work[threadIdx.x] = 0u;
@@ -426,27 +425,33 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     uint32_t cost = 0;                        // quadrant evaluations of this chunk (the backward's cost estimate)
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
+        uint32_t my_mask = 0u;
+        bool past_exit = false;
         if (i < g.end) {
             const uint32_t r = ranks[i];
-            s_rank[lane] = r;
             const float4* R = rec + (size_t)3 * r;
             const float4 a = R[0], b = R[1];
             growth += growth_term(a, b);
-            float4 c = R[2];
-            c.z = __uint_as_float(quad_mask(a, b, c.z, c.w, qx, qy, QE));
+            const float4 c = R[2];
+            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE) & ~dark_quads;
+            if (PASS1) { past_exit = r >= limit; if (past_exit) my_mask = 0u; }      // ranks ascend: everything from the exit rank on is left out
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
+        // the batch's quadrant masks as four wave-uniform bit sets in scalar registers (see chunk_bwd_kernel): no mask read
+        // from LDS per instance, and instances that reach no live quadrant (inside the tile's box but outside the ellipse,
+        // or behind the wall) are never visited
+        const unsigned long long q0 = __builtin_amdgcn_ballot_w64((my_mask & 1u) != 0u), q1 = __builtin_amdgcn_ballot_w64((my_mask & 2u) != 0u);
+        const unsigned long long q2 = __builtin_amdgcn_ballot_w64((my_mask & 4u) != 0u), q3 = __builtin_amdgcn_ballot_w64((my_mask & 8u) != 0u);
+        if (PASS1) { if (__builtin_amdgcn_ballot_w64(past_exit) != 0ull) stop = true; }
         __syncthreads();
-        const uint32_t cnt = min((uint32_t)kCBatch, g.end - bs);
-        for (uint32_t j = 0; j < cnt; j++) {
-            if (PASS1) { if (s_rank[j] >= limit) { stop = true; break; } }
+        for (unsigned long long todo = (q0 | q1) | (q2 | q3); todo != 0ull; ) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);           // front to back
+            todo &= todo - 1ull;
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t mk = __builtin_amdgcn_readfirstlane(__float_as_uint(c.z)) & ~dark_quads;
-            if (mk == 0u) continue;                           // inside the tile's box but outside the ellipse (or behind the wall)
-            cost += (uint32_t)__builtin_popcount(mk);
+            const unsigned long long bit = 1ull << j;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (mk & (1u << k)) {
+                if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
         }
+        cost += (uint32_t)(__popcll(q0) + __popcll(q1)) + (uint32_t)(__popcll(q2) + __popcll(q3));
         __syncthreads();
     }
     const bool publish = n_chunks >= kDeepChunks;            // (pass 1 of a deep view republishes what it recomputed)
@@ -885,11 +891,11 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             todo &= ~(1ull << j);
             const uint32_t slot = (out_lane + j * 9u) * 4u;       // byte offset into s_red
             const float4 a = s_a[j], b = s_b[j], c = s_c[j];
-            const uint32_t mk = (uint32_t)((q0 >> j) & 1ull) | ((uint32_t)((q1 >> j) & 1ull) << 1) | ((uint32_t)((q2 >> j) & 1ull) << 2) | ((uint32_t)((q3 >> j) & 1ull) << 3);
+            const unsigned long long bit = 1ull << j;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (mk & (1u << k)) {
+                if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
                     const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
