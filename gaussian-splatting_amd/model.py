@@ -79,10 +79,19 @@ class GaussianSplat(nn.Module):
         return out
 
     @torch.no_grad()
-    def render_frames(self, camera_poses: torch.Tensor, image_size: Tuple[int, int]) -> torch.Tensor:
+    def render_frames(self, camera_poses: torch.Tensor, image_size: Tuple[int, int], sink=None, block: int = 16):
         """Inference over V poses (V,4,4) -> (V,3,H,W): what the reference's orbit script gets from V calls of
-        `model(pose.unsqueeze(0), size)['rendered_images'][0]` (utils/visualization.py:343-347), in one call."""
-        return render_orbit(self.positions, self.scales, self.rotations, self.opacity, self.features, camera_poses, image_size)
+        `model(pose.unsqueeze(0), size)['rendered_images'][0]` (utils/visualization.py:343-347), in one call.
+        With `sink` (a frames.FrameSink: animated GIF or a directory of PNGs, visualization.py:180-201,244-266) the views are
+        rendered `block` at a time and handed over as they come -- conversion, copy and encoding overlap the next block's
+        rendering, and no (V,3,H,W) tensor is ever held; the number of frames written is returned instead."""
+        if sink is None:
+            return render_orbit(self.positions, self.scales, self.rotations, self.opacity, self.features, camera_poses, image_size)
+        V = camera_poses.shape[0]
+        for v0 in range(0, V, max(1, int(block))):
+            sink.write(render_orbit(self.positions, self.scales, self.rotations, self.opacity, self.features,
+                                    camera_poses[v0:v0 + block], image_size))
+        return V
 
     # ---- maintenance of the parameter buffers (SURVEY 8f row N3; gaussian_splatting.py:346-528).  None of the
     # reference's scripts call these; they are here so that a user of the module finds the same methods.  On the

@@ -518,6 +518,31 @@ def test_orbit_frames_equal_per_view_forward(dev, O):
     assert np.abs(frames[2].cpu().numpy() - fw["rgb"]).max() < RGB_TOL
 
 
+def test_orbit_frames_into_a_sink(dev, tmp_path):
+    """SURVEY 8f N1 with its sink: frames rendered in blocks and written as PNGs through the GPU conversion, the side-stream
+    copy and the worker thread are the bytes the reference's conversion gives for the frames of one render_frames call
+    (utils/visualization.py:254: (frame * 255).astype(uint8); values clamped to [0, 1] first)."""
+    from PIL import Image
+    from gaussian_splatting_amd import GaussianSplat
+    from gaussian_splatting_amd.frames import FrameSink
+    from gaussian_splatting_amd.scenes import create_orbit_poses
+    n, H, W = 1500, 48, 40
+    params = synth_scene(n, 31, 0.01, 0.06)
+    m = GaussianSplat(n)
+    m.load_state_dict({k: torch.from_numpy(params[k]) for k in PARAMS})
+    m = m.to(dev).eval()
+    poses = torch.from_numpy(create_orbit_poses(4.0, 7, 45.0)).to(dev)
+    frames = m.render_frames(poses, (H, W))
+    with FrameSink(tmp_path / "orbit") as sink:
+        assert m.render_frames(poses, (H, W), sink=sink, block=3) == 7
+    want = (frames.clamp(0.0, 1.0).cpu().numpy() * 255).astype(np.uint8).transpose(0, 2, 3, 1)
+    for v in range(7):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "orbit" / f"frame_{v:04d}.png")), want[v]), v
+    with FrameSink(tmp_path / "orbit.gif", fps=12) as sink:
+        m.render_frames(poses, (H, W), sink=sink)
+    assert Image.open(tmp_path / "orbit.gif").n_frames == 7
+
+
 def test_cpu_tensors_fail_loudly():
     from gaussian_splatting_amd import GaussianSplat
     m = GaussianSplat(8)

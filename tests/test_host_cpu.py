@@ -329,3 +329,29 @@ def test_step_struct_layout_matches_header(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [C.sizeof(_lib.GsxStep)] + [getattr(_lib.GsxStep, n).offset for n in names]
+
+
+def test_frame_sink_writes_what_the_reference_would(tmp_path):
+    """SURVEY 8f N1 sink (utils/visualization.py:244-266): (frame * 255).astype(uint8), channels last, PIL -- PNG per frame
+    or an animated GIF; host tensors here, the GPU path is in test_gpu_parity."""
+    from PIL import Image
+    from gaussian_splatting_amd.frames import FrameSink
+    g = torch.Generator().manual_seed(0)
+    frames = torch.rand(5, 3, 12, 16, generator=g)
+    want = (frames.numpy() * 255).astype(np.uint8).transpose(0, 2, 3, 1)                   # the reference's conversion
+    with FrameSink(tmp_path / "png") as sink:
+        sink.write(frames[:3]); sink.write(frames[3]); sink.write(frames[4:])
+    assert sink.count == 5
+    for k in range(5):
+        got = np.asarray(Image.open(tmp_path / "png" / f"frame_{k:04d}.png"))
+        assert np.array_equal(got, want[k]), k
+    with FrameSink(tmp_path / "orbit.gif", fps=10) as sink:
+        sink.write(frames)
+    gif = Image.open(tmp_path / "orbit.gif")
+    assert gif.n_frames == 5 and gif.size == (16, 12) and gif.info["duration"] == 100
+    hot = torch.tensor([[[1.5]], [[-0.2]], [[0.5]]])                                          # out of range: clamped, not wrapped
+    with FrameSink(tmp_path / "clamp") as sink:
+        sink.write(hot)
+    assert np.asarray(Image.open(tmp_path / "clamp" / "frame_0000.png")).tolist() == [[[255, 0, 127]]]
+    with pytest.raises(ValueError):
+        FrameSink(tmp_path / "orbit.mp4")
