@@ -384,7 +384,7 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "device": str(dev), "gpu": torch.cuda.get_device_name(dev)})
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks": seen,
-                "bytes_per_exchange": net.last_allreduce_bytes, "zero_copy_flat_buffer": net.last_sync_was_flat,
+                "bytes_per_exchange": net.last_allreduce_bytes, "zero_copy_flat_buffer": net.last_sync_was_flat, "bytes_copied_to_flatten": net.last_sync_copied_bytes,
                 "schedule": net.schedule, "exchange_ms_on_scratch": net.tuned_ms,
                 "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
                 "exchange_ms_note": "mean over the timed steps, HIP events around the collective on rank 0's stream"}

@@ -31,6 +31,42 @@ def shard_views(n_views, rank, world):
     return list(range(rank, n_views, world))
 
 
+def _adopt_strays(params, grads, tail):
+    """The keep-flat path: the render backward lays all five gradients out in ONE buffer, but a parameter with a second
+    autograd route (the opacity regulariser of the reference's criterion, model/loss.py:100-108) ends up with a fresh
+    tensor -- autograd summed the two routes somewhere else -- while the other four are still views of that buffer.
+    Rather than gathering all 56 N bytes into a new buffer, copy the strays (4 N bytes for the opacity) into their own
+    slots of the buffer the others live in.  Returns (flat view incl. `tail`, bytes copied) or (None, 0)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off); off += p.numel()
+    need = off + tail
+    home = None
+    for g, o in zip(grads, offs):
+        if g is None or not g.is_contiguous():
+            continue
+        base = g.storage_offset() - o
+        st = g.untyped_storage()
+        if base >= 0 and (base + need) * g.element_size() <= st.nbytes():
+            home = (st.data_ptr(), base, g)
+            break
+    if home is None:
+        return None, 0
+    ptr, base, like = home
+    flat_all = torch.empty(0, dtype=like.dtype, device=like.device).set_(like.untyped_storage())
+    flat = flat_all[base:base + need]
+    copied = 0
+    for p, g, o in zip(params, grads, offs):
+        slot = flat[o:o + p.numel()]
+        if g is None:
+            slot.zero_()
+        elif not (g.is_contiguous() and g.untyped_storage().data_ptr() == ptr and g.storage_offset() == base + o):
+            if g.dtype != flat.dtype or g.device != flat.device:
+                return None, 0
+            slot.copy_(g.reshape(-1)); copied += p.numel() * g.element_size()
+    return flat, copied
+
+
 class BalancedViewSampler(torch.utils.data.Sampler):
     """Stands where the reference puts `DistributedSampler(train_dataset)` (scripts/train.py:106-110): every rank draws
     its share of the views of an epoch, all views are visited once (the list is padded by repetition to a multiple of
@@ -175,6 +211,7 @@ class DataParallelSplat(torch.nn.Module):
         self._host_stage = None
         self.last_allreduce_bytes = 0
         self.last_sync_was_flat = None
+        self.last_sync_copied_bytes = 0      # bytes moved to make the gradients one buffer (0: the render's own buffer as it was)
         self.time_exchange = False              # True: HIP events around every exchange, collected in exchange_events
         self.exchange_events = []
         if broadcast and self.active:
@@ -276,6 +313,11 @@ class DataParallelSplat(torch.nn.Module):
         flat = None
         if all(g is not None for g in grads):
             flat = _flat_view_of(grads, FLAG_WORDS)          # the render backward's own buffer: no copy
+        adopted = False
+        self.last_sync_copied_bytes = 0
+        if flat is None and k == len(PARAM_ORDER) and sum(g is not None for g in grads) >= 2:
+            flat, self.last_sync_copied_bytes = _adopt_strays(params, grads, FLAG_WORDS)
+            adopted = flat is not None
         packed = flat is None
         self.last_sync_was_flat = not packed
         total = sum(p.numel() for p in params)
@@ -291,6 +333,7 @@ class DataParallelSplat(torch.nn.Module):
                 else:
                     dst.copy_(g.reshape(-1))
                 off += p.numel()
+            self.last_sync_copied_bytes = total * flat.element_size()
         flags = flat[total:total + FLAG_WORDS]
         pattern = tuple(1.0 if (i < k and grads[i] is not None) else 0.0 for i in range(FLAG_WORDS))
         src = self._flag_cache.get((pattern, dev))
@@ -308,7 +351,7 @@ class DataParallelSplat(torch.nn.Module):
             ev[1].record()
             self.exchange_events.append(ev)
         self.last_allreduce_bytes = flat.numel() * flat.element_size()
-        if packed:
+        if packed or adopted:
             # the averaged gradients stay where they are: .grad becomes a view of the exchange buffer (no copy back), and
             # the five are consecutive again for whoever walks them next (clip_grad_norm_, the fused optimizer)
             seen = flags.tolist() if any(g is None for g in grads) else None

@@ -218,6 +218,24 @@ dp.tune_schedule(14 * N + 8, torch.device("cpu"))
 picks = [None] * world; dist.all_gather_object(picks, (dp.schedule, dp.tuned_ms["mesh"]))
 assert picks == [("allreduce", None)] * world, picks
 assert (dp.tune_error is not None) == (rank == 1)
+# ---- keep-flat: four gradients still in the render backward's buffer, the fifth (opacity: second autograd route) astray --
+m = make(100); dp = DataParallelSplat(m)
+flat = torch.zeros(14 * N + 8)
+g_ = torch.Generator().manual_seed(40 + rank)
+slots = dict(rotations=(0, 4), positions=(4, 3), scales=(7, 3), opacity=(10, 1), features=(11, 3))
+for k_, (o_, w_) in slots.items():
+    v_ = flat[o_ * N:(o_ + w_) * N].view(N, w_); v_.copy_(torch.randn(N, w_, generator=g_)); getattr(m, k_).grad = v_
+stray = m.opacity.grad + 0.25                               # what autograd's sum of two routes leaves: a tensor of its own
+m.opacity.grad = stray
+mine = torch.cat([getattr(m, k_).grad.reshape(-1) for k_ in PARAM_ORDER]).clone()
+both = [torch.empty_like(mine) for _ in range(world)]; dist.all_gather(both, mine)
+dp.sync_gradients()
+assert dp.last_sync_was_flat and dp.last_sync_copied_bytes == 4 * N and dp.last_allreduce_bytes == (14 * N + 8) * 4
+got = torch.cat([getattr(m, k_).grad.reshape(-1) for k_ in PARAM_ORDER])
+assert torch.equal(got, (both[0] + both[1]) / world)
+assert m.opacity.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()     # back in its slot
+assert m.opacity.grad.data_ptr() == flat.data_ptr() + 10 * N * 4
+
 # ---- the view sampler: each rank measured only its own views, one collective completes the table ---------------------
 from gaussian_splatting_amd.distributed import BalancedViewSampler
 true_cost = [100.0 + 50.0 * ((v * 7) % 12) for v in range(12)]
