@@ -105,9 +105,11 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __rest
     const float4 qv = reinterpret_cast<const float4*>(rot)[i];
     const float q[4] = { qv.x, qv.y, qv.z, qv.w };
     Proj o; project_one(p, s, q, M, o);
-    reinterpret_cast<float2*>(mean2d)[i] = make_float2(o.mx, o.my);
-    depth[i] = o.depth;
-    reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
+    if (mean2d) {       // the reference's returned tensors: a caller that never looks at them (a trainer step with an image-only criterion) passes none
+        reinterpret_cast<float2*>(mean2d)[i] = make_float2(o.mx, o.my);
+        depth[i] = o.depth;
+        reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
+    }
     key[i] = depth_key(o.depth);
     // packed copy of everything build_records needs: ONE 48-byte row to gather per Gaussian instead of
     // five scattered lines (mean2d, depth, cov2d, opacity, features)
@@ -350,7 +352,8 @@ GSX_API int gsx_project_fwd(const float* positions, const float* scales, const f
 {
     if (N < 0) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
-    if (!positions || !scales || !rotations || !opacity || !features || !pose || !mean2d || !depth || !cov2d || !depth_key || !pre) return GSX_E_INVALID;
+    if (!positions || !scales || !rotations || !opacity || !features || !pose || !depth_key || !pre) return GSX_E_INVALID;
+    if ((mean2d || depth || cov2d) && !(mean2d && depth && cov2d)) return GSX_E_INVALID;      // all three outputs, or none
     if (((uintptr_t)rotations | (uintptr_t)cov2d | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
     if ((uintptr_t)mean2d & 7u) return GSX_E_INVALID;
     project_fwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(

@@ -88,7 +88,7 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
                              uint32_t* state, int64_t* D_pinned_host, void* count_event, void* stream)
 {
-    if (!positions || !scales || !rotations || !opacity || !features || !pose || !arena || !mean2d || !depth || !cov2d || !rgb || !alpha || !state)
+    if (!positions || !scales || !rotations || !opacity || !features || !pose || !arena || !rgb || !alpha || !state)
         return GSX_E_INVALID;
     if (depth_bits <= 0 || depth_bits > 32 || ((uintptr_t)arena & 255u)) return GSX_E_INVALID;
     Layout L;

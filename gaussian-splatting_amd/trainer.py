@@ -135,8 +135,6 @@ class FusedTrainStep:
         L, S, dev, n = self.L, self.S, self.dev, self.n
         f32 = torch.float32
         self.shape = (H, W)
-        self.mean2d = torch.empty(n, 2, dtype=f32, device=dev); self.depth = torch.empty(n, dtype=f32, device=dev)
-        self.cov2d = torch.empty(n, 2, 2, dtype=f32, device=dev)
         self.rgb = torch.empty(3, H, W, dtype=f32, device=dev); self.alpha = torch.empty(1, H, W, dtype=f32, device=dev)
         self.d_rgb = torch.empty(3, H, W, dtype=f32, device=dev)
         self.state = torch.empty(4, dtype=torch.int32, device=dev)
@@ -144,7 +142,7 @@ class FusedTrainStep:
         wsb = lib.gsx_l1_ssim_workspace_bytes(3, H, W) if self.kind == 2 else lib.gsx_image_loss_workspace_bytes()
         self.loss_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         S.H, S.W = H, W
-        S.mean2d, S.depth, S.cov2d = self.mean2d.data_ptr(), self.depth.data_ptr(), self.cov2d.data_ptr()
+        S.mean2d = S.depth = S.cov2d = None           # the criterion looks at the image only: the projection keeps its 28 B per Gaussian of returned tensors to itself
         S.rgb, S.alpha, S.d_rgb, S.state = self.rgb.data_ptr(), self.alpha.data_ptr(), self.d_rgb.data_ptr(), self.state.data_ptr()
         S.loss_ws, S.loss_ws_bytes = self.loss_ws.data_ptr(), wsb
         self.cap = -1

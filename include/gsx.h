@@ -48,6 +48,8 @@ int gsx_abi_version(void);
  *   mean2d (N,2) = 'positions', depth (N) = 'depths', cov2d (N,2,2) = 'scales',
  * plus depth_key (N) u32: ascending-unsigned order == descending depth (the order
  * torch.argsort(depths, descending=True) produces, :198), -0 folded onto +0.
+ * mean2d / depth / cov2d may be NULL, all three together, for a caller that does not need the returned tensors (a trainer step
+ * whose criterion looks at the image only): 28 of the kernel's 120 bytes per Gaussian less.
  * pre (N x 12 floats): packed copy (mean2d, cov2d, depth, opacity, colour) that gsx_build_records gathers
  * as one 48-byte row per Gaussian. */
 int gsx_project_fwd(const float* positions, const float* scales, const float* rotations,
@@ -306,7 +308,8 @@ typedef struct gsx_step {
     const float* pose;             /* 16 floats */
     const float* target;           /* 3 x H x W */
     void* arena; int64_t arena_bytes;      /* gsx_view_layout(N, H, W, capacity, chunk_force, need_bwd = 1) */
-    float* mean2d; float* depth; float* cov2d; float* rgb; float* alpha;
+    float* mean2d; float* depth; float* cov2d;     /* the reference's returned tensors; all three NULL = not wanted */
+    float* rgb; float* alpha;
     uint32_t* state;               /* 4 x u32, as gsx_composite_fwd */
     float* d_rgb;                  /* 3 x H x W floats of scratch: dLoss/drgb */
     float* loss;                   /* 3 floats: [0] the criterion; GSX_LOSS_L1_SSIM also writes [1] = L1, [2] = SSIM */
