@@ -2,7 +2,6 @@
 (/root/reference/training/trainer.py:144-149; RGB term /root/reference/model/loss.py:126-137), as ONE
 HIP pass each way (csrc/gsx_loss.hip) instead of torch's 6-7 launches.  The reference's full criterion
 also needs VGG16/LPIPS weights from the network (loss.py:34,39) and is out of scope."""
-import ctypes as C
 import torch
 from . import _lib as L
 
