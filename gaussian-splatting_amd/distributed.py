@@ -266,6 +266,18 @@ class DataParallelSplat(torch.nn.Module):
 
     def broadcast_parameters(self, src=0):
         params = [getattr(self.module, k) for k in self._names]
+        own = None
+        if hasattr(self.module, "flatten_parameters") and len(params) == len(PARAM_ORDER):
+            try:
+                own = self.module.flatten_parameters()
+            except RuntimeError:                              # parameters on several devices / dtypes: pack them below
+                own = None
+        if own is not None:                                   # the parameters ARE one buffer: one collective, nothing to pack or unpack
+            if own.is_cuda and dist.get_backend(self.group) != "nccl":
+                host = own.cpu(); dist.broadcast(host, src, group=self.group); own.copy_(host)
+            else:
+                dist.broadcast(own, src, group=self.group)
+            return
         flat = torch.cat([p.data.reshape(-1) for p in params])
         if flat.is_cuda and dist.get_backend(self.group) != "nccl":       # gloo: through the host (see _average)
             host = flat.cpu()

@@ -97,9 +97,53 @@ class GaussianSplat(nn.Module):
     # reference's scripts call these; they are here so that a user of the module finds the same methods.  On the
     # GPU prune and clamp run as HIP passes (csrc/gsx_maint.hip); CPU tensors (host-side tooling) use torch ops.
     def _replace_parameters(self, tensors):
+        was_flat = self.flat_parameters() is not None
         for k, t in zip(("positions", "scales", "rotations", "opacity", "features"), tensors):
             setattr(self, k, nn.Parameter(t))
         self.num_gaussians = int(tensors[0].shape[0])
+        if was_flat:
+            self.flatten_parameters()
+
+    # ---- the five parameters as views of ONE buffer.  Same layout as the gradient buffer the render backward
+    # writes (rotations | positions | scales | opacity | features: rotations first for their 16-byte loads), so that whatever
+    # walks parameters and gradients together -- the broadcast at start-up, an optimizer over slices -- sees two flat arrays.
+    FLAT_ORDER = ("rotations", "positions", "scales", "opacity", "features")
+
+    def flat_parameters(self):
+        """The 14 N buffer the parameters are consecutive views of, or None (never flattened, or re-seated since -- a
+        `.to(device)` moves every parameter on its own)."""
+        flat = getattr(self, "_flat", None)
+        if flat is None:
+            return None
+        off = flat.data_ptr()
+        for k in self.FLAT_ORDER:
+            p = getattr(self, k)
+            if p.data_ptr() != off or not p.is_contiguous() or p.dtype != flat.dtype or p.device != flat.device:
+                self._flat = None                         # stale (the parameters moved): let the old buffer go
+                return None
+            off += p.numel() * p.element_size()
+        return flat
+
+    @torch.no_grad()
+    def flatten_parameters(self):
+        """Re-seats the five parameters (the same nn.Parameter objects: optimizers keep working) as views of one contiguous
+        buffer and returns it.  Maintenance methods that replace the parameters (prune, add, merge) flatten again."""
+        flat = self.flat_parameters()
+        if flat is not None:
+            return flat
+        ps = [getattr(self, k) for k in self.FLAT_ORDER]
+        dev, dt = ps[0].device, ps[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in ps):
+            raise RuntimeError("flatten_parameters: the five parameters must share a device and a dtype")
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=dt, device=dev)
+        off = 0
+        for p in ps:
+            view = flat[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            off += p.numel()
+        self._flat = flat
+        return flat
 
     @torch.no_grad()
     def prune_gaussians(self, threshold: float = 0.01) -> None:

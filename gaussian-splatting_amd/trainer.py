@@ -165,6 +165,7 @@ class FusedTrainStep:
         # the optimizer's own bookkeeping (FusedClipAdam.step): state on first use, one step count for all five
         step = None
         for k, p in enumerate(self.params):
+            S.param[k] = p.data_ptr()                       # a parameter's storage may have been re-seated since the last step
             st = opt.state[p]
             if len(st) == 0:
                 st['step'] = torch.tensor(0.0)

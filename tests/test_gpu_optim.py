@@ -368,3 +368,33 @@ def test_fused_train_step_declines_what_it_cannot_do():
         assert ok() is None
     loss = T.train_step(m, opt, pose, tgt, T.l1_loss, 0.1)            # and the plain case runs
     assert torch.isfinite(loss) and m.positions.grad is not None and opt._fused_step is not None
+
+
+def test_flat_parameters_under_the_fused_step():
+    """Parameters re-seated into one buffer (GaussianSplat.flatten_parameters) in the MIDDLE of training: the
+    one-call step picks the new addresses up, and the run stays bit-equal to one whose parameters never moved."""
+    from gaussian_splatting_amd import GaussianSplat, trainer as T
+    from gaussian_splatting_amd.scenes import create_orbit_poses
+    dev = torch.device("cuda:0")
+    H, W, n = 64, 96, 5000
+    poses = torch.from_numpy(create_orbit_poses(4.0, 60, 45.0)).to(dev)
+    target = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+    out = []
+    for flatten_at in (None, 1):
+        torch.manual_seed(4)
+        m = GaussianSplat(n)
+        with torch.no_grad():
+            m.positions[:, 2] = m.positions[:, 2].abs() * 0.8 + 0.2
+        m = m.to(dev)
+        opt = T.make_optimizer(m, fused_clip_norm=0.1)
+        for s_ in range(4):
+            if s_ == flatten_at:
+                flat = m.flatten_parameters()
+                assert m.flat_parameters() is flat
+            T.train_step(m, opt, poses[3 * s_:3 * s_ + 1], target, T.l1_loss, 0.1)
+        assert opt._fused_step is not None
+        out.append([p.detach().clone() for p in m.parameters()])
+        if flatten_at is not None:
+            assert m.flat_parameters() is not None and torch.equal(m.flat_parameters()[:4 * n].view(n, 4), m.rotations.data)
+    for a, b in zip(*out):
+        assert torch.equal(a, b) and torch.isfinite(a).all()

@@ -355,3 +355,35 @@ def test_frame_sink_writes_what_the_reference_would(tmp_path):
     assert np.asarray(Image.open(tmp_path / "clamp" / "frame_0000.png")).tolist() == [[[255, 0, 127]]]
     with pytest.raises(ValueError):
         FrameSink(tmp_path / "orbit.mp4")
+
+
+def test_flat_parameter_storage():
+    """the five parameters as views of ONE 14 N buffer (same layout as the gradient buffer), without changing
+    the nn.Parameter objects -- optimizers, state dicts and the maintenance methods keep working."""
+    from gaussian_splatting_amd import GaussianSplat
+    torch.manual_seed(3)
+    m = GaussianSplat(50)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ids = {k: id(getattr(m, k)) for k in before}
+    assert m.flat_parameters() is None
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    flat = m.flatten_parameters()
+    assert flat.numel() == 14 * 50 and m.flat_parameters() is flat and m.flatten_parameters() is flat
+    assert {k: id(getattr(m, k)) for k in before} == ids                                   # same Parameter objects
+    off = 0
+    for k in GaussianSplat.FLAT_ORDER:
+        p = getattr(m, k)
+        assert p.data_ptr() == flat.data_ptr() + 4 * off and torch.equal(p.data, before[k]); off += p.numel()
+    (m.positions.sum() + m.opacity.sum()).backward(); opt.step()                          # the optimizer still reaches them ...
+    assert not torch.equal(m.positions.data, before["positions"]) and m.flat_parameters() is flat   # ... in place, in the buffer
+    assert torch.equal(flat[4 * 50:7 * 50].view(50, 3), m.positions.data)
+    m2 = GaussianSplat(50); m2.load_state_dict(m.state_dict())
+    assert all(torch.equal(getattr(m2, k).data, getattr(m, k).data) for k in before)
+    with torch.no_grad():
+        m.opacity.data[::2] = 0.0
+    m.prune_gaussians(0.01)                                                                 # replaces the parameters: flat again
+    assert m.num_gaussians == 25 and m.flat_parameters() is not None and m.flat_parameters().numel() == 14 * 25
+    m.add_gaussians(5)
+    assert m.flat_parameters().numel() == 14 * 30
+    m.double()                                                                              # every parameter re-seated on its own
+    assert m.flat_parameters() is None and getattr(m, "_flat") is None
