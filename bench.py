@@ -375,6 +375,16 @@ def main():
                             "VALU-issue bound (SQ counters in profiles/r2_pmc_sq_counters.json, "
                             "DESIGN.md 4): its HBM fraction is small by construction"}
 
+    # informational, N = 1: BASELINE config 3 read literally (forward-only orbit rendering) next to the headline
+    inference = None
+    if world == 1 and not args.inference:
+        idx = torch.arange(N_VIEWS, device=dev)
+        model.render_frames(poses[idx], (H, W)); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.render_frames(poses[idx], (H, W)); torch.cuda.synchronize()
+        ti = time.perf_counter() - t1
+        inference = {"value": round(N_VIEWS * H * W / ti / 1e6, 1), "unit": "Mpix/s", "ms_per_view": round(ti / N_VIEWS * 1e3, 4),
+                     "what": "forward only, the 60 orbit views in one render_frames call (two streams); not the headline metric"}
     cpu = cpu_c1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # N=1 only: the other ranks would sit in the teardown meanwhile
         cpu, cpu_c1 = cpu_baselines(args, params, H, W, target_cpu[0].numpy())
@@ -413,6 +423,7 @@ def main():
                        "views_timed_rank0": {"count": len(timed_views), "distinct": len(set(timed_views)), "first": timed_views[:8]},
                        **({"gradient_exchange": net.schedule} if use_dp else {})},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "rccl": rccl, "stage_ms": stages,
+            "inference_orbit": inference,
         }
         print(json.dumps(line), flush=True)
     if use_dp:
