@@ -52,6 +52,50 @@ def resolve_scene(root, split) -> SceneFiles:
     return SceneFiles(views, np.ascontiguousarray(poses, dtype=np.float32), info)
 
 
+def write_scene(root, splits, metadata=None, quality=95) -> dict:
+    """Writes a scene in the layout above, as /root/reference/data_processing/preprocessor.py does for its three splits
+    (:177-220 files and poses, :241-247 directories, :262-293 scene_info.json), from views already in memory -- e.g.
+    frames of `GaussianSplat.render_frames` -- rather than from a raw capture directory.
+    splits: {'train'|'val'|'test': (views, poses)} with views (n, H, W, 3) uint8 or (n, 3, H, W) float in [0, 1] (array or
+    tensor) and poses (n, 4, 4).  Splits left out are written empty, so every split of the result resolves.
+    Files are named '<split>_<index:06d>.jpg' (name order = pose order), JPEG quality 95 (OpenCV's default; the encoded
+    bytes are PIL's, not OpenCV's: "parity unpinned" for them, the layout and the JSON keys are the reference's).
+    Returns the scene_info dict."""
+    from PIL import Image
+    root = os.fspath(root)
+    unknown = set(splits) - set(SPLITS)
+    if unknown:
+        raise ValueError(f"unknown split(s) {sorted(unknown)}: a scene has {', '.join(SPLITS)}")
+    sizes, image_size = {}, None
+    os.makedirs(os.path.join(root, 'poses'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'metadata'), exist_ok=True)
+    for split in SPLITS:
+        views, poses = splits.get(split, (np.zeros((0, 1, 1, 3), np.uint8), np.zeros((0, 4, 4), np.float32)))
+        if torch.is_tensor(views):
+            views = views.detach().cpu().numpy()
+        if torch.is_tensor(poses):
+            poses = poses.detach().cpu().numpy()
+        views, poses = np.asarray(views), np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
+        if views.ndim != 4 or len(views) != len(poses):
+            raise ValueError(f"split {split!r}: {views.shape} views but poses of shape {poses.shape}")
+        if views.dtype != np.uint8:                                       # (n, 3, H, W) in [0, 1] -> (n, H, W, 3) bytes
+            views = np.rint(np.clip(views.transpose(0, 2, 3, 1), 0.0, 1.0) * 255.0).astype(np.uint8)
+        if views.shape[-1] != 3:
+            raise ValueError(f"split {split!r}: views must be (n, H, W, 3) uint8 or (n, 3, H, W) float, got {views.shape}")
+        folder = os.path.join(root, 'images', split)
+        os.makedirs(folder, exist_ok=True)
+        for i, rgb in enumerate(views):
+            Image.fromarray(np.ascontiguousarray(rgb)).save(os.path.join(folder, f"{split}_{i:06d}.jpg"), quality=quality)
+        np.save(os.path.join(root, 'poses', split + '_poses.npy'), poses)
+        sizes[split] = len(views)
+        if len(views):
+            image_size = [int(views.shape[2]), int(views.shape[1])]         # (W, H), the reference's order
+    info = {'metadata': dict(metadata or {}), 'processing': {'image_size': image_size, 'splits': sizes}}
+    with open(os.path.join(root, 'metadata', 'scene_info.json'), 'w') as f:
+        json.dump(info, f, indent=4)
+    return info
+
+
 class SceneDataset(Dataset):
     def __init__(self, data_path, split='train', transform=None, image_size=None):
         self.files = resolve_scene(data_path, split)

@@ -271,4 +271,41 @@ def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad
     return loss.detach()
 
 
+def train_epoch(model, optimizer, views, loss_fn=l1_loss, max_grad_norm=0.1):
+    """One pass over `views` -- an iterable of (image (1,3,H,W), camera_pose (1,4,4), ...) already on the model's device,
+    i.e. what dataset.DevicePrefetcher yields -- with train_step per view; the loop of trainer.py:128-207 without its
+    logging.  Returns the mean loss like the reference, but sums on the device and reads it back once at the end: the
+    reference's per-step loss.item() (:178) would stall the stream every step."""
+    model.train()
+    total, n = None, 0
+    for view in views:
+        loss = train_step(model, optimizer, view[1], view[0], loss_fn, max_grad_norm)
+        total = loss.clone() if total is None else total.add_(loss)        # the fused step returns a view of its own buffer
+        n += 1
+    return float(total) / n if n else 0.0
+
+
+@torch.no_grad()
+def evaluate(model, views):
+    """Mean L1, MSE and PSNR (of images in [0,1]: -10 log10 MSE, per view, then averaged) over `views` (as for
+    train_epoch), under no_grad -- the image metrics of the reference's validation pass (trainer.py:209-240) that need
+    no network weights.  One read-back at the end."""
+    was_training = model.training
+    model.eval()
+    acc, n = None, 0
+    for view in views:
+        image, pose = view[0], view[1]
+        c = model(pose, image.shape[-2:])['rendered_images']
+        d = c - image
+        mse = (d * d).mean()
+        row = torch.stack([d.abs().mean(), mse, -10.0 * torch.log10(mse.clamp_min(1e-12))])
+        acc = row if acc is None else acc.add_(row)
+        n += 1
+    model.train(was_training)
+    if not n:
+        return {'l1': 0.0, 'mse': 0.0, 'psnr': 0.0, 'views': 0}
+    l1, mse, psnr = (acc / n).tolist()
+    return {'l1': l1, 'mse': mse, 'psnr': psnr, 'views': n}
+
+
 _FUSED_LOSSES.update({l1_loss: (0, 0.0), clamped_mse_loss: (1, 0.0), l1_ssim_loss: (2, 0.2)})

@@ -315,6 +315,32 @@ def test_scene_dataset_follows_reference_format(tmp_path):
     assert len(got) == 2 and got[0][0].shape == (1, 3, 12, 16) and got[0][1].shape == (1, 4, 4) and got[1][2].endswith("0000.jpg")
 
 
+def test_write_scene_round_trips_through_the_reader(tmp_path):
+    """The writer side of the N2 format (data_processing/preprocessor.py:177-220,241-247,262-293): directories, file
+    names, pose file, scene_info.json keys; what it writes is what SceneDataset reads."""
+    import json
+    from gaussian_splatting_amd.dataset import SceneDataset, write_scene
+    rng = np.random.default_rng(3)
+    blocky = lambda n: np.kron(rng.integers(0, 255, (n, 3, 4, 3)), np.ones((1, 4, 4, 1))).astype(np.uint8)       # (n, 12, 16, 3)
+    poses = np.tile(np.eye(4), (6, 1, 1)); poses[:, :3, 3] = rng.standard_normal((6, 3))
+    tr, va = blocky(4), blocky(2)
+    info = write_scene(tmp_path / "s", {"train": (tr, poses[:4]), "val": (torch.from_numpy(va).permute(0, 3, 1, 2).float() / 255.0, torch.from_numpy(poses[4:]))},
+                       metadata={"scene_name": "s"})
+    assert info == json.load(open(tmp_path / "s" / "metadata" / "scene_info.json"))
+    assert info["processing"] == {"image_size": [16, 12], "splits": {"train": 4, "val": 2, "test": 0}} and info["metadata"]["scene_name"] == "s"
+    assert sorted(os.listdir(tmp_path / "s" / "images" / "train")) == [f"train_{i:06d}.jpg" for i in range(4)]
+    ds = SceneDataset(tmp_path / "s", "train")
+    assert len(ds) == 4 and np.array_equal(ds.files.poses, poses[:4].astype(np.float32))
+    assert np.abs(ds.view_u8(3).astype(np.float32) - tr[3]).mean() < 20                                    # lossy JPEG of the view written
+    dv = SceneDataset(tmp_path / "s", "val")
+    assert len(dv) == 2 and np.abs(dv.view_u8(1).astype(np.float32) - va[1]).mean() < 20                   # float CHW input, same bytes
+    assert len(SceneDataset(tmp_path / "s", "test")) == 0                                                  # a split left out resolves, empty
+    with pytest.raises(ValueError):
+        write_scene(tmp_path / "t", {"holdout": (tr, poses[:4])})
+    with pytest.raises(ValueError):
+        write_scene(tmp_path / "t", {"train": (tr, poses[:3])})
+
+
 def test_step_struct_layout_matches_header(tmp_path):
     """gsx_train_step takes a struct: the ctypes mirror (_lib.GsxStep) must have the header's size and field offsets."""
     import ctypes as C, shutil, subprocess
