@@ -308,4 +308,36 @@ def evaluate(model, views):
     return {'l1': l1, 'mse': mse, 'psnr': psnr, 'views': n}
 
 
+def save_checkpoint(path, model, optimizer, epoch, loss, scheduler=None, **extra):
+    """The reference's checkpoint file (trainer.py:242-271): a dict with 'epoch', 'model_state_dict' (prefix-free, also
+    for a data-parallel wrapper), 'optimizer_state_dict', 'loss' and, when given, 'scheduler_state_dict'; tensors and
+    plain containers only, so torch.load(weights_only=True) reads it.  (The reference also pickles its config object into
+    the file; pass what you need of it as plain values through **extra.)  FusedClipAdam's state has torch.optim.Adam's
+    layout, so either optimizer resumes from the other's file."""
+    inner = model.module if hasattr(model, "module") else model
+    ckpt = {'epoch': int(epoch), 'model_state_dict': inner.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
+            'loss': float(loss)}
+    if scheduler is not None:
+        ckpt['scheduler_state_dict'] = scheduler.state_dict()
+    ckpt.update(extra)
+    torch.save(ckpt, path)
+    return ckpt
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location=None):
+    """Restores what save_checkpoint (or the reference's trainer, minus its pickled config: weights_only=True refuses
+    that key's class, by design) wrote and returns the epoch to resume from, like trainer.py:273-295.  Keys saved from
+    inside a DistributedDataParallel ('module.' prefix) are accepted; a Gaussian count other than the model's raises, as
+    load_state_dict does (GaussianSplat.load_state is the call that resizes)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    inner = model.module if hasattr(model, "module") else model
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt['model_state_dict'].items()}
+    inner.load_state_dict(sd)
+    if optimizer is not None and 'optimizer_state_dict' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+    if scheduler is not None and 'scheduler_state_dict' in ckpt:
+        scheduler.load_state_dict(ckpt['scheduler_state_dict'])
+    return int(ckpt['epoch']) + 1
+
+
 _FUSED_LOSSES.update({l1_loss: (0, 0.0), clamped_mse_loss: (1, 0.0), l1_ssim_loss: (2, 0.2)})

@@ -341,6 +341,36 @@ def test_write_scene_round_trips_through_the_reader(tmp_path):
         write_scene(tmp_path / "t", {"train": (tr, poses[:3])})
 
 
+def test_checkpoint_file_has_the_reference_layout(tmp_path):
+    """trainer.py:242-295: keys of the file, prefix-free model keys, epoch + 1 on resume, optimizer state restored."""
+    from gaussian_splatting_amd import GaussianSplat, trainer as T
+    torch.manual_seed(0)
+    m = GaussianSplat(40)
+    opt = T.make_optimizer(m)
+    for p in m.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt)
+    path = tmp_path / "checkpoint_0003.pt"
+    T.save_checkpoint(path, m, opt, epoch=3, loss=0.25, scheduler=sched, image_size=[100, 75])
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss", "image_size"}
+    assert set(raw["model_state_dict"]) == {"positions", "scales", "rotations", "opacity", "features"} and raw["epoch"] == 3
+    m2 = GaussianSplat(40)
+    opt2 = T.make_optimizer(m2)
+    assert T.load_checkpoint(path, m2, opt2) == 4
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert s1.keys() == s2.keys() and all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1)
+    raw["model_state_dict"] = {"module." + k: v for k, v in raw["model_state_dict"].items()}       # as saved from inside DDP
+    torch.save(raw, path)
+    m3 = GaussianSplat(40)
+    assert T.load_checkpoint(path, m3) == 4 and torch.equal(m3.positions, m.positions)
+    with pytest.raises(RuntimeError):
+        T.load_checkpoint(path, GaussianSplat(41))
+
+
 def test_step_struct_layout_matches_header(tmp_path):
     """gsx_train_step takes a struct: the ctypes mirror (_lib.GsxStep) must have the header's size and field offsets."""
     import ctypes as C, shutil, subprocess
