@@ -178,27 +178,30 @@ __global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __res
 // ------------------------------------------------------------------------------------------
 // Forward occlusion skipping.  The chunk pass composites all chunks of a tile in parallel, blind to the transmittance in
 // front of them; in a dense view a third to a half of the instances sit behind a wall of earlier splats (and in a
-// config-5-like scene nine tenths).  Every chunk therefore PUBLISHES, when it is done,
-//   * a payload: per pixel, the DARKNESS q = floor(-4 log2 |T_local|) of what it lets through, in quarter-bits, rounded
-//     towards "brighter" (one byte per pixel: 64 words per chunk, lane l holds its own four pixels), and
-//   * a header: the chunk's bound on how much |T| can GROW inside it, in quarter-bits (0 unless an opacity lies outside
-//     [0, 2]; a NaN/inf transmittance or a bound above 15 bits makes the chunk UNBOUNDED).
-// Integer sums of the payloads of a tile's chunks 0..k-1 bound -log2 |T| on entry to chunk k, per pixel.  The rule, per
-// 8x8 QUADRANT w of the tile (64 pixels = one wave of the combine pass = one lane-quadruple slot of the chunk pass):
-//   dark(c, w)  <=>  no unbounded chunk before c  and  every pixel p of w has  sum_c(p) >= 4 GSX_CUT_LOG2 + growth(c)
-//   sum_{c+1}(p) = sum_c(p) - growth(c)   if dark(c, w)      (whatever the chunk would have done there, it cannot have
-//                = sum_c(p) + q_c(p)      otherwise           raised |T| by more than its growth bound)
-// In a dark quadrant every weight T * alpha is below 2^-GSX_CUT_LOG2, the bound under which the footprint cut drops pairs.
-// The combine pass evaluates the recursion from the published words -- integers, a function of the data alone -- and
-// treats a dark quadrant of a chunk as the identity WHETHER OR NOT it was computed, so the image does not depend on timing.
-// A chunk may therefore leave out every quadrant it can PROVE dark from what is published when it starts (the same
-// recursion over the chunks in front of it; a quadrant that is not dark needs the payload of that chunk, a dark one only
-// its header), and skip itself when all four are.  Payloads of chunks in front of a dark point always exist: a quadrant
-// that is not dark is always computed.  Workgroups are dispatched in LEVEL order (every tile's chunk 0, then every tile's
-// chunk 1, ...; chunk_order_kernel builds the table), so that by the time the deep chunks of a tile start, its shallow ones
-// have finished.  No waiting anywhere: a chunk that cannot tell yet computes.
+// config-5-like scene five sixths).  Every chunk therefore PUBLISHES, when it is done, a payload: per pixel, the DARKNESS
+// q = floor(-4 log2 |T_local|) of what it lets through, in quarter-bits, rounded towards "brighter" (one byte per pixel:
+// 64 words per chunk, lane l holds its own four pixels).  Integer sums of the payloads of a tile's chunks 0..k-1 bound
+// -log2 |T| on entry to chunk k, per pixel.  The rule, per 8x8 QUADRANT w of the tile (64 pixels = one wave of the
+// combine pass = one lane-quadruple slot of the chunk pass):
+//   w is DARK from the first level L on at which every pixel p of w has  sum_{c < L} q_c(p)  >=  4 GSX_CUT_LOG2 + G(tile),
+//   G(tile) = the growth bounds of ALL the tile's chunks together: by how much |T| can grow inside them, in quarter-bits
+//   (0 unless an opacity lies outside [0, 2]: the header pass below; a chunk that bounds nothing -- NaN/inf transmittance,
+//   15 bits and more -- makes its tile UNBOUNDED: nothing of it is ever dark).
+// Behind L every weight T * alpha of the quadrant is below 2^-GSX_CUT_LOG2 (the entry bound times whatever the chunks from L
+// on can add), the bound under which the footprint cut drops pairs.  The combine pass evaluates the rule from the
+// published words -- integers, a function of the data alone -- and treats a dark quadrant of a chunk as the identity
+// WHETHER OR NOT it was computed, so the image does not depend on timing.  A chunk may therefore leave out every quadrant
+// it can PROVE dark when it starts, and skip itself when all four are.  Payloads of chunks in front of a dark point
+// always exist: a quadrant that is not dark is always computed.  Workgroups are dispatched in LEVEL order (every tile's
+// chunk 0, then every tile's chunk 1, ...; chunk_order_kernel builds the table), so that by the time the deep chunks of
+// a tile start, its shallow ones have finished.  No waiting anywhere: a chunk that cannot tell yet computes.
+// (Round 2's first rule tested each chunk against 4 GSX_CUT_LOG2 + its OWN growth and took that growth off the sums of a
+// dark chunk: exact, but not monotone -- behind the dark point the sums stand still, every grower drains them, and a
+// chunk's proof needed the headers of everything in front of it.  A dozen trainer steps push a few hundred of six million
+// opacities below 0; that tripled the chunk pass of a config-5 view.)
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHdrDone = 0x80000000u, kHdrUnbounded = 0x40000000u, kHdrGrowthMask = 0xFFFFFu;
+constexpr uint32_t kDeepChunks = 20480;                // a view is DEEP from this many chunks on (see chunk_order_kernel)
 constexpr int kDarkQ = 4 * GSX_CUT_LOG2;               // quarter-bits of darkness at which every weight is below the cut
 constexpr int kPayBias = 65;                           // payload byte = q + 65 in [1, 255] (0 = not published): q in [-64, 190]
 // tail of the chunk-state buffer behind the states, in words per chunk: meta 1, dark 1, work lists 2 x kWorkClasses (+ 16
@@ -239,70 +242,155 @@ __device__ __forceinline__ int darkness_q(float m, int e)
     return max(-64, min(190, q));
 }
 
-// Entry darkness of chunk k of a tile from what is published NOW: s[w] = this lane's pixel of quadrant w.  false = cannot
-// tell (a chunk in front has not finished, or is unbounded): the caller computes everything.
-// returns 0, or why not: 2 = a header is missing or unbounded, 3 = a needed payload is missing (kept in the low byte of the
-// chunk's meta word as a diagnostic: tools/skip_stats.py)
-__device__ __forceinline__ int entry_darkness(const uint32_t* hdr_t, const uint32_t* pay_t, uint32_t k, int lane, int s[4])
+// Entry darkness of chunk k of a tile.  Returns the quadrants PROVEN dark (bits 0..3) | a reason code << 8 (1 = level 0,
+// 2 = an unbounded chunk in the tile, 3 = nothing proven and a payload was missing, 4 = nothing proven, 5 = some quadrants
+// are dark; kept in the low byte of the chunk's meta word as a diagnostic: tools/skip_stats.py).  Whatever is not proven is
+// computed, so a proof only has to be SOUND (never call dark what the rule of the combine pass does not), and everything
+// below errs to that side: a word that is read too early, or stale, reads as "not there".
+// The rule is monotone -- a quadrant is dark from the first level on at which its payload sums reach the tile's threshold
+// -- so the proof is made once per (tile, quadrant): the first dark level is a fact about the data, whoever finds it; it
+// is kept in tile_first[w] (kDarkUnknown until found; atomicMin), and a chunk reads four words and is done.
+// Finding it means summing the payloads of the chunks in front from level 0 (`walk`); a quadrant whose next payload is
+// not there yet is given up for this call, the others go on.  Who walks:
+//   * a chunk of the first kWalkAll levels when it STARTS (cheap, and the shallow dark points are found at once);
+//   * a chunk when it is DONE, for the entry of its successor (own payload included), at every fourth of the first levels
+//     and behind them at levels of the form m * 2^e, m = 4..7: every next walk is at most a quarter deeper than the last,
+//     so a dark point at level L is known by level 1.25 L while a tile's walks together read ~5 x its depth in payloads --
+//     a quadrant at the rim of the scene never gets dark, and its tile must not walk its whole list again for every chunk.
+//     Why at the end: the chunks of a tile that is not dark yet all compute, and once most other tiles skip, the machine
+//     dispatches them faster than they finish -- a chunk that starts finds the last dozens of payloads in front of it
+//     missing.  A chunk that is done started after its predecessors and took as long: their payloads are there.
+// Coherence.  The eight XCDs' L2s are not coherent with each other, and the words read here (levels, "published" bits,
+// payloads) are written by other chunks of the same launch: an `sc1` load is served by the reader's own L2, and a line
+// that this XCD has loaded before a store from elsewhere may stay stale for as long as it is re-read.  Every such error
+// goes the safe way -- an unknown level, a bit that is not up yet, a zero payload word all read as "not there": the chunk
+// computes -- so what is skipped depends on timing and placement, what the image is does not.  A payload is only loaded
+// once its chunk's bit is up (so that a walk does not pull a line of zeros into its XCD's L2 for the walks after it), and
+// zeros under a raised bit are taken for what they are.  Measured on a config-5 view (1.9 G instances, 7.6 M chunks, the
+// rule calls 84 % of the chunks dark): 40 % skip themselves, a quarter of the tiles learn a quadrant's level hundreds of
+// levels late or never (one XCD in eight sees it); reading the words with read-modify-write atomics instead (an OR with an
+// opaque zero, device or system scope) changed neither, and a lock-protected running sum per tile (every payload read
+// once) was slower.  What the pass costs now is mostly the chunks that compute in vain: 100 ms against 350 ms before the
+// header pass and the monotone rule, ~40 ms if every dark chunk skipped.
+constexpr uint32_t kDarkUnknown = 0xFFFFFFFFu, kTileUnbounded = 0x80000000u, kHdrPublished = 0x40000000u, kWalkAll = 64;
+__device__ __forceinline__ uint32_t sc1_read(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool walk_level(uint32_t k)         // the levels whose entry is examined by the chunk in front, when it is done
 {
-    s[0] = s[1] = s[2] = s[3] = 0;
-    for (uint32_t base = 0; base < k; base += 64) {
-        const uint32_t idx = base + (uint32_t)lane;
-        const uint32_t hv = idx < k ? __hip_atomic_load(hdr_t + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kHdrDone;
-        if (__builtin_amdgcn_ballot_w64(hv == 0u || (hv & kHdrUnbounded))) return 2;
-        const uint32_t cnt = min(64u, k - base);
-        // no grower among these chunks and all four quadrants dark already: they are all dark and change nothing
-        if (!__builtin_amdgcn_ballot_w64((hv & kHdrGrowthMask) != 0u) &&
-            !__builtin_amdgcn_ballot_w64(s[0] < kDarkQ || s[1] < kDarkQ || s[2] < kDarkQ || s[3] < kDarkQ)) continue;
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
-            uint32_t pw[8];
+    if (k < kWalkAll) return (k & 3u) == 0u;
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(k);      // k = m * 2^(e-2) + rest, m = 4..7
+    return (k & ((1u << (e - 2u)) - 1u)) == 0u;
+}
+__device__ __forceinline__ uint32_t entry_walk(const uint32_t* hdr_t, const uint32_t* pay_t, uint32_t* tile_first, uint32_t k, int lane, uint32_t tile_growth, bool walk)
+{
+    if (k == 0u) return 1u << 8;
+    if (!tile_first) return 4u << 8;                          // (an image with more tiles than the work lists' room holds words for)
+    if (tile_growth & kTileUnbounded) return 2u << 8;
+    const int thr = kDarkQ + (int)tile_growth;
+    uint32_t trk = 0xFu, dark = 0u, missing = 0u;
+    const uint32_t head = sc1_read(tile_first + (lane & 3));  // (a per-lane address: a uniform one becomes a scalar load, another cache)
 #pragma unroll
-            for (int u = 0; u < 8; u++)            // eight payloads in flight (most are needed: the dark point is rarely far)
-                pw[u] = (j0 + u < cnt) ? __hip_atomic_load(pay_t + (size_t)(base + j0 + u) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+    for (int w = 0; w < 4; w++) {
+        const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)head, w);
+        if (L != kDarkUnknown) { trk &= ~(1u << w); if (L <= k) dark |= 1u << w; }
+    }
+    if (trk == 0u || !walk) return dark | ((dark ? 5u : 4u) << 8);
+    uint32_t first[4] = { kDarkUnknown, kDarkUnknown, kDarkUnknown, kDarkUnknown };
+    int s[4] = { 0, 0, 0, 0 };
+#pragma unroll 1
+    for (uint32_t j0 = 0; j0 < k && trk != 0u; j0 += 8) {
+        // which of the next eight chunks have published (lane u asks for chunk j0 + u)
+        uint32_t fl = 0u;
+        if (lane < 8 && j0 + (uint32_t)lane < k) fl = sc1_read(hdr_t + j0 + lane);
+        const uint32_t there8 = (uint32_t)__builtin_amdgcn_ballot_w64((fl & kHdrPublished) != 0u) & 0xffu;
+        uint32_t pw[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (j0 + u < cnt) {
-                    const int gq = (int)((uint32_t)__shfl((int)hv, (int)(j0 + u), 64) & kHdrGrowthMask);
-                    const int thr = kDarkQ + gq;
-                    bool d[4];
+        for (int u = 0; u < 8; u++)            // eight payloads in flight
+            pw[u] = ((there8 >> u) & 1u) ? __hip_atomic_load(pay_t + (size_t)(j0 + u) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-                    for (int w = 0; w < 4; w++) d[w] = __builtin_amdgcn_ballot_w64(s[w] < thr) == 0ull;
-                    if (!(d[0] && d[1] && d[2] && d[3]) && __builtin_amdgcn_ballot_w64(pw[u] == 0u)) return 3;   // not finished yet
+        for (int u = 0; u < 8; u++) {
+            if (j0 + u < k) {
+                // a published word is never 0: zeros under a raised bit are a stale line (the payloads are not line-aligned: the
+                // neighbour's read brought this one's first or last words in too early)
+                const bool there = ((there8 >> u) & 1u) != 0u && __builtin_amdgcn_ballot_w64(pw[u] == 0u) == 0ull;
 #pragma unroll
-                    for (int w = 0; w < 4; w++) s[w] = d[w] ? s[w] - gq : s[w] + (int)((pw[u] >> (8 * w)) & 0xffu) - kPayBias;
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t bit = 1u << w;
+                    if (trk & bit) {
+                        if (__builtin_amdgcn_ballot_w64(s[w] < thr) == 0ull) {                // dark from this level on
+                            first[w] = j0 + (uint32_t)u; trk &= ~bit; dark |= bit;
+                        } else if (there) {
+                            s[w] += (int)((pw[u] >> (8 * w)) & 0xffu) - kPayBias;
+                        } else {                                                              // not finished yet: give this one up
+                            trk &= ~bit; missing |= bit;
+                        }
+                    }
                 }
             }
         }
     }
-    return 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if ((trk & (1u << w)) && __builtin_amdgcn_ballot_w64(s[w] < thr) == 0ull) { first[w] = k; dark |= 1u << w; }
+    if (lane == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) if (first[w] != kDarkUnknown) atomicMin(tile_first + w, first[w]);
+    }
+    return dark | ((dark ? 5u : missing ? 3u : 4u) << 8);
 }
 
-// The part of the chunk pass that only a DEEP view runs: publishes the chunk's header, then tries to prove quadrants dark.
-// Returns dark quadrants (bits 0..3) | reason code << 8.
-__device__ __forceinline__ uint32_t deep_prologue(const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, uint32_t cb, uint32_t chunk,
-                                               uint32_t begin, uint32_t end, uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pay, int lane)
+// ------------------------------------------------------------------------------------------
+// Header pass of a deep view (two small launches in front of the chunk pass): the growth of every tile, in the header
+// word of the tile's FIRST chunk (hdr[chunk_base[tile]]: sum of its chunks' bounds in quarter-bits | kTileUnbounded).
+//   grower_bitmap_kernel: one bit per RANK -- can this splat make |T| grow (opacity outside [0, 2], or an improper
+//     exponent)? -- and their number.  Almost always zero: then the second launch returns at once (the words are zero).
+//   tile_growth_kernel: one wave per chunk tests its ranks against the bitmap (L2-resident: N / 8 bytes) and reads the
+//     records of the growers only; a chunk's bound (the same terms in the same order as the chunk pass's own sum for the
+//     backward's cut) goes into its tile's word.  Integer additions: the total does not depend on their order.  Without a
+//     bitmap (no room: see the host side) every record is read.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void grower_bitmap_kernel(const float4* __restrict__ rec, uint32_t N, const uint32_t* __restrict__ chunk_base,
+                                                               int n_tiles, uint32_t max_chunks, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ count)
 {
-    const uint32_t level = chunk - cb;
-    // The header goes out FIRST: a chunk's growth bound is a function of its records alone (same terms, same order as the
-    // staging loop of the chunk pass), and it is all that a later chunk needs of a DARK one -- which may still be running,
-    // or be skipping itself, when that later chunk starts.  Payloads are only needed of chunks in front of the dark point.
-    float pre = 0.0f;
-    for (uint32_t i = begin + lane; i < end; i += kCBatch) {
-        const float4* R = rec + (size_t)3 * ranks[i];
-        pre += growth_term(R[0], R[1]);
+    if (min(chunk_base[n_tiles], max_chunks) < kDeepChunks) return;
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;      // N is rounded up to whole waves: every lane reaches the ballot
+    bool grower = false;
+    if (r < N) { const float4* R = rec + (size_t)3 * r; grower = growth_term(R[0], R[1]) != 0.0f; }      // NaN counts
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(grower);
+    if ((threadIdx.x & 63) == 0 && r < N) {                    // (a wave wholly past the end has no words: the count sits there)
+        bitmap[(r >> 5)] = (uint32_t)m; bitmap[(r >> 5) + 1] = (uint32_t)(m >> 32);
+        if (m) atomicAdd(count, (uint32_t)__popcll(m));
     }
-    const uint32_t hw = header_word(wave_sum(pre));
-    if (lane == 0) __hip_atomic_store(hdr + chunk, hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ds[4];
-    uint32_t why = level == 0 ? 1u : (hw & kHdrUnbounded) ? 2u : (uint32_t)entry_darkness(hdr + cb, pay + (size_t)cb * 64, level, lane, ds);
-    uint32_t dark_quads = 0;
-    if (why == 0u) {
-        const int thr = kDarkQ + (int)(hw & kHdrGrowthMask);
-#pragma unroll
-        for (int w = 0; w < 4; w++) dark_quads |= (__builtin_amdgcn_ballot_w64(ds[w] < thr) == 0ull) ? (1u << w) : 0u;
-        why = dark_quads ? 5u : 4u;                           // 4 = no quadrant is dark enough, 5 = some are (left out)
+}
+
+constexpr int kHeaderBlocks = 4096;
+__global__ __launch_bounds__(kBlock) void tile_growth_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ chunk_base, int n_tiles, int tw, uint32_t max_chunks,
+                                                             const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ count, uint32_t* __restrict__ hdr)
+{
+    const uint32_t n_chunks = min(chunk_base[n_tiles], max_chunks);
+    if (n_chunks < kDeepChunks) return;
+    if (bitmap && *count == 0u) return;                       // no grower in the view: every tile's word stays 0
+    const int lane = threadIdx.x & 63;
+    for (uint32_t chunk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * (kBlock / 64)) {
+        const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+        float pre = 0.0f;
+        bool any = false;
+        for (uint32_t i = g.begin + lane; i < g.end; i += kCBatch) {
+            const uint32_t r = ranks[i];
+            if (!bitmap || ((bitmap[r >> 5] >> (r & 31u)) & 1u)) {
+                const float4* R = rec + (size_t)3 * r;
+                pre += growth_term(R[0], R[1]);
+                any = true;
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(any)) continue;
+        const uint32_t hw = header_word(wave_sum(pre));
+        if (lane == 0) {
+            uint32_t* word = hdr + chunk_base[g.tile];
+            if (hw & kHdrUnbounded) atomicOr(word, kTileUnbounded);
+            else if (hw & kHdrGrowthMask) atomicAdd(word, hw & kHdrGrowthMask);
+        }
     }
-    return dark_quads | (why << 8);
 }
 
 // Level-order work table: order_tab[i] = chunk id, all tiles' chunk 0 first (tile order), then all chunk 1s, ...  Workgroup l
@@ -315,7 +403,6 @@ constexpr int kOrderThreads = 1024, kOrderLevels = 256;
 // proven in time, and reading the predecessors' payloads only costs (measured: +25 % on the chunk pass, no chunk skipped).
 // A view is DEEP from this many chunks on (a function of the data, like everything the rule depends on); below it nothing is
 // published, nothing skipped, and the combine pass ignores the rule.
-constexpr uint32_t kDeepChunks = 20480;
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t* total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,14 +421,17 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
 
 __global__ __launch_bounds__(kOrderThreads) void chunk_order_kernel(const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t max_chunks,
                                                                     uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay,
-                                                                    uint32_t* __restrict__ order_tab)
+                                                                    uint32_t* __restrict__ order_tab, uint32_t* __restrict__ tile_dark)
 {
     __shared__ uint32_t s_w[kOrderThreads / 64];
     const uint32_t l = blockIdx.x, n_chunks = min(chunk_base[n_tiles], max_chunks);
     if (n_chunks < kDeepChunks) return;                       // a shallow view: no table, and every word is written before it is read
-    // "not published": headers and payloads of this view's chunks (not of the buffers' capacity)
+    // "not published": payloads of this view's chunks (not of the buffers' capacity); header words (the tiles' growth) and
+    // first dark levels start from nothing
     for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_chunks; i += (size_t)gridDim.x * kOrderThreads) hdr[i] = 0u;
     for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_chunks * 64; i += (size_t)gridDim.x * kOrderThreads) pay[i] = 0u;
+    if (tile_dark)
+        for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_tiles * 4; i += (size_t)gridDim.x * kOrderThreads) tile_dark[i] = kDarkUnknown;
     const bool tail = blockIdx.x == gridDim.x - 1;
     uint32_t below = 0;                                       // chunks of the levels before l
     for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
@@ -366,12 +456,17 @@ __global__ __launch_bounds__(kOrderThreads) void chunk_order_kernel(const uint32
 // ------------------------------------------------------------------------------------------
 // F1: one wave per chunk, local compositing from (C = 0, T = 1)
 // ------------------------------------------------------------------------------------------
-template <bool PASS1, bool DEPTH>
+// DEEP: the instantiation for deep views (level order, forward occlusion skipping); the other one never looks at a header.
+// Which of the two a view needs is known on the device only: both are launched when the buffers could hold a deep view,
+// and the one that does not apply returns at once.  (One kernel with the deep prologue behind a branch, round 2's first
+// version, tied the shallow path's register allocation to the prologue's shape: 92 VGPRs became 117-120 when the walk
+// gained its shortcuts.)
+template <bool PASS1, bool DEPTH, bool DEEP>
 __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t N, int H, int W, int tw, float stepx, float stepy,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
-    uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay, const uint32_t* __restrict__ order_tab)
+    uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay, const uint32_t* __restrict__ order_tab, uint32_t* __restrict__ tile_dark)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     if (!PASS1 && blockIdx.x == 0) {          // the combine pass (next launch) counts in these; pass 0 itself reads neither
@@ -379,6 +474,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         if (threadIdx.x < 16) work[threadIdx.x] = 0u;
     }
     const uint32_t n_chunks = chunk_base[n_tiles];
+    if (!PASS1 && DEEP != (n_chunks >= kDeepChunks)) return;          // the other instantiation's view
     uint32_t limit = N;
     if (PASS1) { limit = rank_limit_from_state(state, N); if (limit >= N) return; }
     const int lane = threadIdx.x;
@@ -387,16 +483,15 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     // them -- and walks the chunks with a grid stride when it does run.
     for (uint32_t blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
     // pass 0 of a deep view walks the chunks in level order (the table of chunk_order_kernel); otherwise the stride walk
-    const bool deep = !PASS1 && n_chunks >= kDeepChunks;
+    constexpr bool deep = DEEP;
     const uint32_t chunk = deep ? order_tab[blk] : chunk_of_block(blk, n_chunks);
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
-    // quadrants proven dark on entry: left out (the combine pass ignores them anyway).  The zero comes out of an asm
-    // statement so that the compiler does not know it: knowing it, it clones the whole compositing loop for shallow views
-    // (twice the code, and measurably slower for both).
-    uint32_t dark_quads, why = 0;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(dark_quads));
+    // quadrants proven dark on entry: left out (the combine pass ignores them anyway)
+    uint32_t dark_quads = 0, why = 0;
     if (deep) {
-        const uint32_t pre = deep_prologue(rec, ranks, chunk_base[g.tile], chunk, g.begin, g.end, hdr, pay, lane);
+        const uint32_t cb = chunk_base[g.tile];
+        const uint32_t pre = entry_walk(hdr + cb, pay + (size_t)cb * 64, tile_dark ? tile_dark + 4 * (size_t)g.tile : nullptr, chunk - cb, lane,
+                                        hdr[cb] & ~kHdrPublished, chunk - cb < kWalkAll);
         dark_quads = pre & 0xFu; why = pre >> 8;
         if (dark_quads == 0xFu) {                             // every quadrant dark on entry: nothing to do
             if (lane == 0) chunk_meta[chunk] = 0u;
@@ -474,7 +569,8 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         renorm(m[k], e[k]);
-        if (publish) payload |= (uint32_t)(darkness_q(m[k], e[k]) + kPayBias) << (8 * k);
+        // (a pixel outside the image shows nothing: it must not keep its quadrant from getting dark)
+        if (publish) payload |= (uint32_t)(((x0 + ((k & 1) << 3) < W && y0 + ((k >> 1) << 3) < H) ? darkness_q(m[k], e[k]) : 190) + kPayBias) << (8 * k);
         const int pix = k * 64 + lane;
         *state_ptr(chunk_state, chunk, 0, pix) = C0[k];
         *state_ptr(chunk_state, chunk, 1, pix) = C1[k];
@@ -486,12 +582,19 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     growth = wave_sum(growth);
     // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
     const uint32_t gbits = (growth == 0.0f) ? 0u : (growth < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)growth + 2u : (uint32_t)GSX_META_GROWTH_MAX;
-    // publish: payload (every lane its own word), then the header.  A reader that finds the header takes the payload's
-    // word for what it is: zero = not there yet.
+    // publish the payload (every lane its own word; zero = not there yet)
     if (publish) __hip_atomic_store(pay + (size_t)chunk * 64 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
         chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT) | why;
-        if (publish) __hip_atomic_store(hdr + chunk, header_word(growth), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (DEEP) {
+        // every lane's word is on its way before the chunk's bit goes up; then, done: look for the tile's dark points on
+        // behalf of the chunks behind (entry_walk)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_or(hdr + chunk, kHdrPublished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cb = chunk_base[g.tile], k1 = chunk - cb + 1u;
+        if (k1 < chunk_base[g.tile + 1] - cb && walk_level(k1))
+            entry_walk(hdr + cb, pay + (size_t)cb * 64, tile_dark ? tile_dark + 4 * (size_t)g.tile : nullptr, k1, lane, hdr[cb] & ~kHdrPublished, true);
     }
     if (!PASS1) break;                        // compile-time: pass 0 has no back edge
     __syncthreads();
@@ -530,7 +633,10 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     // been passed (nothing is dark behind one).  One wave = one 8x8 quadrant, so the quadrant's verdict is a ballot.
     // Only in a DEEP view (kDeepChunks: a function of the view's chunk count): shallow views neither publish nor skip.
     int dsum = 0;
-    bool blocked = chunk_base[n_tiles] < kDeepChunks;
+    const uint32_t tile_growth = (c1 > c0 && chunk_base[n_tiles] >= kDeepChunks) ? (hdr[c0] & ~kHdrPublished) : kTileUnbounded;
+    const bool blocked = (tile_growth & kTileUnbounded) != 0u;
+    const int dark_thr = kDarkQ + (int)(tile_growth & ~kTileUnbounded);
+    bool for_good = false;                    // this wave's quadrant has passed its dark point
     uint32_t skipped = 0;                     // bit u: this quadrant of chunk u of the (last) batch is dark -- the identity, computed or not
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l5[kCombineBatch];
@@ -550,16 +656,8 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         for (int u = 0; u < kCombineBatch; u++) {
             const uint32_t c = cb + u;
             if (c < c1) {
-                int gq = 0;
-                bool qdark = false;
-                if (!blocked) {
-                    const uint32_t hw = hdr[c];
-                    gq = (int)(hw & kHdrGrowthMask);
-                    if (hw & kHdrUnbounded) blocked = true;
-                    else qdark = __builtin_amdgcn_ballot_w64(dsum < kDarkQ + gq) == 0ull;
-                }
-                if (qdark) {                                  // the identity here, whether or not the chunk pass computed it
-                    dsum -= gq;
+                if (!blocked && !for_good) for_good = __builtin_amdgcn_ballot_w64(dsum < dark_thr) == 0ull;
+                if (for_good) {                               // the identity here, whether or not the chunk pass computed it
                     skipped |= 1u << u;
                     if (need_bwd && (threadIdx.x & 63) == 0) {
                         reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = 0x81;      // dark (bit 0), by this rule (bit 7)
@@ -960,20 +1058,40 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     const float sx = lin_step(W), sy = lin_step(H);
     const float4* r4 = (const float4*)rec;
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
-    const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
     uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
+    const bool could_be_deep = (uint64_t)max_chunks >= kDeepChunks;
+    // first dark level per (tile, quadrant) of a deep view (entry_walk): in the work lists' room, which the combine pass only
+    // fills after the chunk pass (none if the image has more tiles than that holds: then nothing is skipped)
+    uint32_t* tile_dark = (could_be_deep && 4 * (size_t)n_tiles <= 2 * (size_t)kWorkClasses * (size_t)max_chunks) ? work + 16 : nullptr;
+    // the shallow instantiation only has work below kDeepChunks chunks: its grid need not be larger
+    const dim3 gc((unsigned)max_chunks), gc0((unsigned)(could_be_deep ? kDeepChunks - 1 : max_chunks)), gt((unsigned)n_tiles);
     uint32_t* hdr = meta + tail_hdr_offset((size_t)max_chunks);                             // published headers, level-order table, payloads
     uint32_t* order_tab = hdr + max_chunks;
     uint32_t* pay = order_tab + max_chunks;
     if (max_chunks <= 0) clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // otherwise block 0 of the chunk pass clears them
-    else if ((uint64_t)max_chunks >= kDeepChunks)           // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
-        chunk_order_kernel<<<dim3(kOrderLevels), dim3(kOrderThreads), 0, st>>>(chunk_base, n_tiles, (uint32_t)max_chunks, hdr, pay, order_tab);
+    else if (could_be_deep) {                               // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
+        // the level-order table (its kernel also clears the payloads and the tiles' words), then the header pass: four
+        // launches that return at once unless the view at hand is deep.  The grower bitmap (2 words per 64 ranks + the
+        // count) borrows the head of the chunk states, which nothing writes before the chunk pass; a model too large
+        // even for that gets its headers from the records.
+        chunk_order_kernel<<<dim3(kOrderLevels), dim3(kOrderThreads), 0, st>>>(chunk_base, n_tiles, (uint32_t)max_chunks, hdr, pay, order_tab, tile_dark);
+        const size_t bm_words = ((size_t)N + 63) / 64 * 2;
+        uint32_t* bitmap = (N > 0 && bm_words + 1 <= (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) ? reinterpret_cast<uint32_t*>(chunk_state) : nullptr;
+        if (bitmap) {
+            GSX_HIP(hipMemsetAsync(bitmap + bm_words, 0, sizeof(uint32_t), st));
+            grower_bitmap_kernel<<<dim3((unsigned)(((size_t)N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st>>>(r4, (uint32_t)N, chunk_base, n_tiles, (uint32_t)max_chunks, bitmap, bitmap + bm_words);
+        }
+        tile_growth_kernel<<<dim3(kHeaderBlocks), dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, tw, (uint32_t)max_chunks,
+                                                                      bitmap, bitmap ? bitmap + bm_words : nullptr, hdr);
+    }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_kernel<false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+        if (max_chunks > 0) chunk_fwd_kernel<false, true, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
+        if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     } else {
-        if (max_chunks > 0) chunk_fwd_kernel<false, false><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+        if (max_chunks > 0) chunk_fwd_kernel<false, false, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
+        if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
@@ -981,10 +1099,10 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
-            chunk_fwd_kernel<true, true><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+            chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
             tile_combine_kernel<true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         } else {
-            chunk_fwd_kernel<true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab);
+            chunk_fwd_kernel<true, false, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
             tile_combine_kernel<true, false><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         }
     }

@@ -26,11 +26,11 @@ for v in views:
     h0 = 2 * mc + 16 + 10 * mc
     hdr = tail[h0:h0 + nch]
     pay = tail[h0 + 2 * mc: h0 + 2 * mc + 64 * nch].reshape(nch, 64)
-    skipped = int(((hdr != 0) & (pay[:, 0] == 0)).sum()); unpublished = int((hdr == 0).sum())
+    skipped = int((pay[:, 0] == 0).sum()); unpublished = 0
     db = dark.view(np.uint8).reshape(nch, 4)
     darkrun = int((db == 0x81).all(1).sum()); darkq = int((db == 0x81).sum())
     print(f"view {v}: D={vs.D} chunks={nch} all-4-quadrants-dark={darkrun} ({darkrun / max(nch, 1):.0%}) dark quadrants={darkq / max(4 * nch, 1):.0%} "
-          f"self-skipped={skipped} ({skipped / max(nch, 1):.0%}) unpublished={unpublished} unbounded={int(((hdr & 0x40000000) != 0).sum())} "
+          f"self-skipped={skipped} ({skipped / max(nch, 1):.0%}) unpublished={unpublished} unbounded tiles={int(((hdr & 0x80000000) != 0).sum())} "
           f"composite_fwd={tot['composite_fwd'][0]:.3f} ms", flush=True)
     # where the dark point lies: per tile, the level of its first all-dark chunk
     cbase = vs.chunk_base.cpu().numpy().view(np.uint32)[:-1].astype(np.int64)
