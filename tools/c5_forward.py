@@ -27,8 +27,8 @@ for v in views:
     pay0 = tail[h0 + 2 * mc: h0 + 2 * mc + 64 * nch].view(-1, 64)[:, 0].cpu().numpy().view(np.uint32)
     db = tail[mc:mc + nch].cpu().numpy().view(np.uint8).reshape(nch, 4)
     meta = tail[0:nch].cpu().numpy().view(np.uint32) & 0xff
-    print("   why not skipped (1 level 0, 2 header missing/unbounded, 3 payload missing, 4 not dark, 5 partly dark, 0 skipped or shallow view):",
+    print("   why not skipped (1 level 0, 2 unbounded tile, 3 nothing proven and a payload missing, 4 nothing proven, 5 partly dark, 0 skipped or shallow view):",
           {int(k): int(c) for k, c in zip(*np.unique(meta, return_counts=True))})
     print(f"view {v}: D={vs.D} chunks={nch} forward {min(ts):.2f} ms; chunks dark by the rule {int((db == 0x81).all(1).sum()) / nch:.1%}, "
-          f"skipped by the chunk pass {int(((hdr != 0) & (pay0 == 0)).sum()) / nch:.1%}, unbounded headers {int(((hdr & 0x40000000) != 0).sum())}, growers {int(((hdr & 0xFFFFF) != 0).sum())}, checksum {float(outs[0].double().sum()):.6f}", flush=True)
+          f"skipped by the chunk pass {int((pay0 == 0).sum()) / nch:.1%}, unbounded tiles {int(((hdr & 0x80000000) != 0).sum())}, tiles with growth {int(((hdr & 0x3FFFFFFF) != 0).sum())}, checksum {float(outs[0].double().sum()):.6f}", flush=True)
     del outs, vs, tail
