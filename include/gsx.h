@@ -155,7 +155,9 @@ int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W, int32_t chunk_force);
  * list is cut into chunks of 64 / 128 / GSX_CHUNK instances (chunk_base[n_tiles + 1]); one wave64 composites one chunk for the whole
  * 16x16 tile (4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
  * the chunks (compositing is associative), writes the image and -- with need_bwd -- each chunk's dark-quadrant
- * bytes and the backward's work lists.  Enqueues, in order: chunk pass,
+ * bytes and the backward's work lists.  Enqueues, in order: (only when max_chunks could hold a deep view, 20480
+ * chunks and more: the level-order table and the header pass of the forward occlusion skipping -- launches that return at
+ * once for a shallow view --) chunk pass,
  * combine pass, exact early-exit search (only does work when every pixel saturated: the
  * reference's global exit, :147), and a second chunk + combine pass that only does work when the
  * exit fired before the last Gaussian.
