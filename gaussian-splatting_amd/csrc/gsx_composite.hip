@@ -260,18 +260,13 @@ __device__ __forceinline__ int darkness_q(float m, int e)
 //     Why at the end: the chunks of a tile that is not dark yet all compute, and once most other tiles skip, the machine
 //     dispatches them faster than they finish -- a chunk that starts finds the last dozens of payloads in front of it
 //     missing.  A chunk that is done started after its predecessors and took as long: their payloads are there.
-// Coherence.  The eight XCDs' L2s are not coherent with each other, and the words read here (levels, "published" bits,
-// payloads) are written by other chunks of the same launch: an `sc1` load is served by the reader's own L2, and a line
-// that this XCD has loaded before a store from elsewhere may stay stale for as long as it is re-read.  Every such error
-// goes the safe way -- an unknown level, a bit that is not up yet, a zero payload word all read as "not there": the chunk
-// computes -- so what is skipped depends on timing and placement, what the image is does not.  A payload is only loaded
-// once its chunk's bit is up (so that a walk does not pull a line of zeros into its XCD's L2 for the walks after it), and
-// zeros under a raised bit are taken for what they are.  Measured on a config-5 view (1.9 G instances, 7.6 M chunks, the
-// rule calls 84 % of the chunks dark): 40 % skip themselves, a quarter of the tiles learn a quadrant's level hundreds of
-// levels late or never (one XCD in eight sees it); reading the words with read-modify-write atomics instead (an OR with an
-// opaque zero, device or system scope) changed neither, and a lock-protected running sum per tile (every payload read
-// once) was slower.  What the pass costs now is mostly the chunks that compute in vain: 100 ms against 350 ms before the
-// header pass and the monotone rule, ~40 ms if every dark chunk skipped.
+// Visibility.  The words read here (levels, "published" bits, payloads) are written by other chunks of the same launch,
+// on any XCD, with `sc1` stores or atomics, and read with `sc1` loads (which bypass this CU's L1; a per-lane address where
+// the address is wave-uniform, so that the load does not become a scalar one through yet another cache).  The XCDs' L2s
+// are not coherent with each other, so a reader may see an old value for a while.  Every such error goes the safe way --
+// an unknown level, a bit that is not up yet, a zero payload word all read as "not there": the chunk computes -- so what
+// is skipped depends on timing and placement, what the image is does not.  A payload is only loaded once its chunk's
+// bit is up, and zeros under a raised bit (the payloads are not line-aligned) are taken for "not there" as well.
 constexpr uint32_t kDarkUnknown = 0xFFFFFFFFu, kTileUnbounded = 0x80000000u, kHdrPublished = 0x40000000u, kWalkAll = 64;
 __device__ __forceinline__ uint32_t sc1_read(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool walk_level(uint32_t k)         // the levels whose entry is examined by the chunk in front, when it is done
@@ -280,7 +275,8 @@ __device__ __forceinline__ bool walk_level(uint32_t k)         // the levels who
     const uint32_t e = 31u - (uint32_t)__builtin_clz(k);      // k = m * 2^(e-2) + rest, m = 4..7
     return (k & ((1u << (e - 2u)) - 1u)) == 0u;
 }
-__device__ __forceinline__ uint32_t entry_walk(const uint32_t* hdr_t, const uint32_t* pay_t, uint32_t* tile_first, uint32_t k, int lane, uint32_t tile_growth, bool walk)
+__device__ __forceinline__ uint32_t entry_walk(const uint32_t* hdr_t, const uint32_t* pay_t, uint32_t* tile_first, uint32_t k, int lane,
+                                               uint32_t tile_growth, bool walk)
 {
     if (k == 0u) return 1u << 8;
     if (!tile_first) return 4u << 8;                          // (an image with more tiles than the work lists' room holds words for)
@@ -394,8 +390,8 @@ __global__ __launch_bounds__(kBlock) void tile_growth_kernel(const float4* __res
 }
 
 // Level-order work table: order_tab[i] = chunk id, all tiles' chunk 0 first (tile order), then all chunk 1s, ...  Workgroup l
-// writes level l: its offset is sum_t min(n_t, l), a tile's slot its rank among the tiles that reach the level.  The last
-// workgroup takes every level from kOrderLevels - 1 on, tile by tile.  Also clears the published headers and payloads.
+// writes the levels l, l + kOrderLevels, ...: a level's offset is sum_t min(n_t, l), a tile's slot its rank among the tiles
+// that reach the level.  Also clears the published headers and payloads.
 constexpr int kOrderThreads = 1024, kOrderLevels = 256;
 // Skipping pays where a tile's list is many rounds of the machine deep: then the chunks that decide a tile's dark point have
 // long finished when its deep chunks start.  In a shallow view (config 3: <= 10 k chunks on ~5 k wave slots, dark points
@@ -424,7 +420,7 @@ __global__ __launch_bounds__(kOrderThreads) void chunk_order_kernel(const uint32
                                                                     uint32_t* __restrict__ order_tab, uint32_t* __restrict__ tile_dark)
 {
     __shared__ uint32_t s_w[kOrderThreads / 64];
-    const uint32_t l = blockIdx.x, n_chunks = min(chunk_base[n_tiles], max_chunks);
+    const uint32_t n_chunks = min(chunk_base[n_tiles], max_chunks);
     if (n_chunks < kDeepChunks) return;                       // a shallow view: no table, and every word is written before it is read
     // "not published": payloads of this view's chunks (not of the buffers' capacity); header words (the tiles' growth) and
     // first dark levels start from nothing
@@ -432,24 +428,28 @@ __global__ __launch_bounds__(kOrderThreads) void chunk_order_kernel(const uint32
     for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_chunks * 64; i += (size_t)gridDim.x * kOrderThreads) pay[i] = 0u;
     if (tile_dark)
         for (size_t i = (size_t)blockIdx.x * kOrderThreads + threadIdx.x; i < (size_t)n_tiles * 4; i += (size_t)gridDim.x * kOrderThreads) tile_dark[i] = kDarkUnknown;
-    const bool tail = blockIdx.x == gridDim.x - 1;
-    uint32_t below = 0;                                       // chunks of the levels before l
-    for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
-        const int t = t0 + (int)threadIdx.x;
-        if (t < n_tiles) below += min(chunk_base[t + 1] - chunk_base[t], l);
-    }
-    uint32_t level_off;
-    block_excl_scan_1024(below, s_w, &level_off);
-    if (level_off >= n_chunks) return;                        // no tile is this deep (uniform)
-    uint32_t carry = level_off;
-    for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
-        const int t = t0 + (int)threadIdx.x;
-        uint32_t cb = 0, cnt = 0;
-        if (t < n_tiles) { cb = chunk_base[t]; const uint32_t n = chunk_base[t + 1] - cb; cnt = n > l ? (tail ? n - l : 1u) : 0u; }
-        uint32_t tot;
-        const uint32_t pos = carry + block_excl_scan_1024(cnt, s_w, &tot);
-        for (uint32_t j = 0; j < cnt; j++) order_tab[pos + j] = cb + l + j;
-        carry += tot;
+    // workgroup b writes the levels b, b + gridDim.x, ...: level order all the way down.  (First version: the last
+    // workgroup wrote everything from level kOrderLevels - 1 on tile by tile -- the deep end of every tile was dispatched
+    // in one burst, a thousand chunks of one tile in flight together, none of which could know anything about the other.)
+    for (uint32_t l = blockIdx.x; ; l += gridDim.x) {
+        uint32_t below = 0;                                   // chunks of the levels before l
+        for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
+            const int t = t0 + (int)threadIdx.x;
+            if (t < n_tiles) below += min(chunk_base[t + 1] - chunk_base[t], l);
+        }
+        uint32_t level_off;
+        block_excl_scan_1024(below, s_w, &level_off);
+        if (level_off >= n_chunks) return;                    // no tile is this deep (uniform)
+        uint32_t carry = level_off;
+        for (int t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
+            const int t = t0 + (int)threadIdx.x;
+            uint32_t cb = 0, cnt = 0;
+            if (t < n_tiles) { cb = chunk_base[t]; cnt = chunk_base[t + 1] - cb > l ? 1u : 0u; }
+            uint32_t tot;
+            const uint32_t pos = carry + block_excl_scan_1024(cnt, s_w, &tot);
+            if (cnt && pos < max_chunks) order_tab[pos] = cb + l;
+            carry += tot;
+        }
     }
 }
 
