@@ -24,7 +24,7 @@ SYMBOLS = [
     "gsx_comm_available", "gsx_comm_unique_id", "gsx_comm_init", "gsx_allreduce_avg", "gsx_bcast", "gsx_comm_destroy",
 ]
 
-ABI_VERSION = 17            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 18            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE, GSX_E_AGAIN, GSX_E_COMM = 0, -1, -2, -3, -4, -5, -6
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -94,7 +94,7 @@ def lib():
     L.gsx_view_layout.restype = _i64; L.gsx_view_layout.argtypes = [_i32, _i32, _i32, _i64, _i32, _i32, _p, _p]
     L.gsx_view_forward.argtypes = [_p] * 6 + [_i32, _i32, _i32, _i64, _i32, _p, _i32, _i32, _p, _i64] + [_p] * 7 + [_p, _p, _p]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
-    L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p]
+    L.gsx_composite_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _i64, _p]
     L.gsx_preprocess_bwd.argtypes = [_p] * 12 + [_i32, _i32] + [_p] * 6
     L.gsx_clip_adam_workspace_bytes.restype = _sz
     L.gsx_clip_adam_step.argtypes = [_i32, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64, C.c_float,

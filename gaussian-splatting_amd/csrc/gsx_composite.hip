@@ -888,7 +888,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
-    const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials)
+    const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
@@ -925,6 +925,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t dark_mask = (dw & 1u) | ((dw >> 7) & 2u) | ((dw >> 14) & 4u) | ((dw >> 21) & 8u);
     {
         if (dark_mask == 0xFu) {
+            if (prezeroed) return;            // the host zero-filled every row up front (deep views: gsx_composite_bwd)
             for (uint32_t i = g.begin + lane; i < eff_end; i += 64) {
                 const uint32_t r = ranks[i];
                 const float2 bb = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rec) + (size_t)GSX_REC_FLOATS * r + 10);
@@ -1113,21 +1114,28 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
 GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
                               const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                               int64_t max_chunks, const float* chunk_state, const uint32_t* state,
-                              const float* d_rgb, float* partials, void* stream)
+                              const float* d_rgb, float* partials, int64_t n_rows, void* stream)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
     if (N == 0 || max_chunks == 0) return GSX_OK;
     if (!rec || !ranks_sorted || !ranges || !chunk_base || !offsets || !chunk_state || !state || !d_rgb || !partials) return GSX_E_INVALID;
     if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
+    if (n_rows < 0) return GSX_E_INVALID;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
+    // A view of tens of millions of instances is mostly occluded chunks, whose rows are zeros: filling all rows in one
+    // streaming pass and letting those chunks return at once beats having each of them find its rows' places (two gathers
+    // per instance) and write 36 scattered bytes there (config 5, 1.9 G instances: backward 147 -> see DESIGN).  A small
+    // view has few such chunks and the fill would only cost.
+    const int prezeroed = n_rows >= GSX_PREZERO_ROWS ? 1 : 0;
+    if (prezeroed) GSX_HIP(hipMemsetAsync(partials, 0, (size_t)n_rows * 9 * sizeof(float), (hipStream_t)stream));
     chunk_bwd_kernel<<<dim3((unsigned)max_chunks), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state,
         reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile),
         reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + max_chunks,
         reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + 2 * (size_t)max_chunks,
-        d_rgb, partials);
+        d_rgb, partials, prezeroed);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -179,7 +179,7 @@ GSX_API int gsx_train_step(const gsx_step* s, void* stream)
     float* partials = reinterpret_cast<float*>(arena + L.off[GSX_VIEW_PARTIALS]);
     st = gsx_composite_bwd(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), u32(GSX_VIEW_OFFSETS),
                            s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,
-                           s->d_rgb, partials, stream);
+                           s->d_rgb, partials, D, stream);
     if (st != GSX_OK) return st;
     st = gsx_preprocess_bwd(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
                             u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, nullptr, nullptr, nullptr, s->N, 0,

@@ -296,6 +296,9 @@ _ARENA_FIELDS = frozenset(("order", "rank_of", "rec", "tt", "offsets", "tiles", 
 # GSX_STAGED=1: render through the stage entry points (one allocation per buffer, one FFI call per stage) instead of
 # gsx_view_forward; a stage timer (bench.py's per-kernel HIP events) selects that path too.  Same launches either way.
 STAGED = os.environ.get("GSX_STAGED", "0") == "1"
+# backward_view tells gsx_composite_bwd the view's instance count, so that a very large view (GSX_PREZERO_ROWS and more) gets
+# its partial rows zero-filled in one pass instead of by its occluded chunks; False: never (tests compare the two)
+PREZERO_ROWS = True
 
 
 def forward_view(params, pose, H, W, order=None, want_depth=True, need_bwd=True):
@@ -464,7 +467,7 @@ def backward_view(params, vs, d_rgb, d_mean2d, d_depth, d_cov2d, grads, accumula
         with _stage("composite_bwd"):
             L.check(lib.gsx_composite_bwd(vs.ptr("rec"), vs.ptr("ranks"), vs.ptr("ranges"), vs.ptr("chunk_base"), vs.ptr("offsets"),
                                           n, vs.H, vs.W, vs.max_chunks, vs.ptr("chunk_state"), vs.ptr("state"),
-                                          _ptr(d_rgb), _ptr(partials), _stream()), "gsx_composite_bwd")
+                                          _ptr(d_rgb), _ptr(partials), int(vs.D) if PREZERO_ROWS else 0, _stream()), "gsx_composite_bwd")
     with _stage("preprocess_bwd"):
       L.check(lib.gsx_preprocess_bwd(_ptr(positions), _ptr(scales), _ptr(rotations),
                                    _ptr(vs.pose), vs.ptr("rank_of"), vs.ptr("offsets"), vs.ptr("tt"),

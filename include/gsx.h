@@ -39,7 +39,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 17
+#define GSX_ABI_VERSION 18
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -211,11 +211,16 @@ int gsx_view_forward(const float* positions, const float* scales, const float* r
  * that chunk: all its weights T*alpha stay below 2^-23, like the pairs the footprint cut drops.  A chunk with four
  * dark quadrants gets zero rows without evaluating a pair.  gridDim = max_chunks: the chunks are taken from the
  * work lists the forward's combine pass left in chunk_state (costliest first).
- *   partials: >= D rows of 9 floats. */
+ *   partials: >= D rows of 9 floats.
+ *   n_rows: the view's instance count D as the caller knows it (rows 0 .. n_rows - 1 exist and are this view's), or 0.
+ *       From GSX_PREZERO_ROWS on the call zero-fills those rows in one pass up front and occluded chunks write nothing
+ *       (a view that large is mostly occluded chunks); below it, and with 0, every chunk writes its own rows.  Same
+ *       results either way. */
+#define GSX_PREZERO_ROWS (16ll << 20)
 int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
                       const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                       int64_t max_chunks, const float* chunk_state, const uint32_t* state,
-                      const float* d_rgb, float* partials, void* stream);
+                      const float* d_rgb, float* partials, int64_t n_rows, void* stream);
 
 /* ---- backward of records + projection: sums each splat's partial rows, then chains through
  * the 2x2 inverse, J*Sigma3*J^T, R(q)diag(s^2)R(q)^T, quaternion normalisation and the

@@ -508,6 +508,31 @@ def test_forward_occlusion_skipping_deep_view(dev, O, growers):
         assert rel_err(g[k], go[k]) < GRAD_RTOL, k
 
 
+def test_backward_rows_zero_filled_up_front_equal_rows_zeroed_by_chunks(dev):
+    """gsx_composite_bwd with the view's instance count (>= GSX_PREZERO_ROWS = 16 Mi: one fill, occluded chunks write
+    nothing) against the same call without it (every chunk writes its rows): the five gradients bit for bit.  A view of
+    screen-sized splats: every splat in every tile, 24 M instances, most chunks occluded."""
+    from gaussian_splatting_amd import render as R
+    rng = np.random.default_rng(11)
+    n, H, W = 60000, 320, 320
+    params = synth_scene(n, 83, 0.5, 1.0, o_lo=0.3, o_hi=1.0)
+    d_rgb = rng.standard_normal((3, H, W)).astype(np.float32)
+    gp = gpu_pipeline(params, pose_tz(2.0), H, W, dev)
+    assert gp["_t"]["D"] >= 16 << 20, gp["_t"]["D"]
+    dark, _, _ = _chunk_tail(gp["_t"])
+    assert ((dark & 1) != 0).all(1).mean() > 0.3                  # occluded chunks: the ones whose rows are at stake
+    assert R.PREZERO_ROWS
+    g_fill = gpu_backward(gp, H, W, d_rgb)
+    R.PREZERO_ROWS = False
+    try:
+        g_own = gpu_backward(gp, H, W, d_rgb)
+    finally:
+        R.PREZERO_ROWS = True
+    for k in PARAMS:
+        assert np.array_equal(g_fill[k], g_own[k]), k
+        assert np.isfinite(g_fill[k]).all() and np.abs(g_fill[k]).max() > 0, k
+
+
 def test_orbit_frames_equal_per_view_forward(dev, O):
     """render_frames(V poses) == V module forwards (bitwise), and == the oracle within 1e-4."""
     from gaussian_splatting_amd import GaussianSplat
