@@ -607,7 +607,9 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 // local colour by the colour BEHIND it (per unit transmittance at the chunk's end).
 // state[1] is raised if some pixel is clearly not saturated (the global early exit cannot fire).
 // ------------------------------------------------------------------------------------------
-template <bool PASS1, bool DEPTH>
+// DEEP: as for the chunk pass -- the instantiation without it is the shallow views' (no rule, no payload, no header: the
+// bench scene's kernel), the one with it the deep views' and pass 1's; in pass 0 the one that does not apply returns at once.
+template <bool PASS1, bool DEPTH, bool DEEP>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
+    if (!PASS1 && DEEP != (chunk_base[n_tiles] >= kDeepChunks)) return;              // the other instantiation's view
     const int pix = threadIdx.x;
     // pass 0: one tile per workgroup; pass 1 (a no-op unless the global early exit fired): small grid, grid stride
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -633,24 +636,29 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     // been passed (nothing is dark behind one).  One wave = one 8x8 quadrant, so the quadrant's verdict is a ballot.
     // Only in a DEEP view (kDeepChunks: a function of the view's chunk count): shallow views neither publish nor skip.
     int dsum = 0;
-    const uint32_t tile_growth = (c1 > c0 && chunk_base[n_tiles] >= kDeepChunks) ? (hdr[c0] & ~kHdrPublished) : kTileUnbounded;
+    const uint32_t tile_growth = (DEEP && c1 > c0 && chunk_base[n_tiles] >= kDeepChunks) ? (hdr[c0] & ~kHdrPublished) : kTileUnbounded;
     const bool blocked = (tile_growth & kTileUnbounded) != 0u;
     const int dark_thr = kDarkQ + (int)(tile_growth & ~kTileUnbounded);
-    bool for_good = false;                    // this wave's quadrant has passed its dark point
+    bool for_good = false;                    // this wave's quadrant has passed its dark point (never without DEEP: `blocked`)
     uint32_t skipped = 0;                     // bit u: this quadrant of chunk u of the (last) batch is dark -- the identity, computed or not
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l5[kCombineBatch];
         skipped = 0;
         // lane u of every wave fetches chunk cb + u's flag word together with the states; the scan below reads it as a lane
         // broadcast (a scalar load inside the dependent scan is one more memory latency per chunk)
-        const uint32_t meta_l = (need_bwd && (threadIdx.x & 63) < kCombineBatch) ? chunk_meta[min(cb + (threadIdx.x & 63u), c1 - 1)] : 0u;
+        // (a quadrant that is past its dark point needs none of this: in a deep tile that is most of the list -- the states
+        // of a config-5 view are 5 KB a chunk, and reading them all cost as much as the chunk pass)
+        uint32_t meta_l = 0u;
+        if (!for_good) {
+            if (need_bwd && (threadIdx.x & 63) < kCombineBatch) meta_l = chunk_meta[min(cb + (threadIdx.x & 63u), c1 - 1)];
 #pragma unroll
-        for (int u = 0; u < kCombineBatch; u++) {
-            const uint32_t c = min(cb + u, c1 - 1);
-            l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
-            l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
-            l4[u] = *state_ptr(chunk_state, c, 4, pix);
-            l5[u] = DEPTH ? *state_ptr(chunk_state, c, 5, pix) : 0.f;
+            for (int u = 0; u < kCombineBatch; u++) {
+                const uint32_t c = min(cb + u, c1 - 1);
+                l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
+                l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
+                l4[u] = *state_ptr(chunk_state, c, 4, pix);
+                l5[u] = DEPTH ? *state_ptr(chunk_state, c, 5, pix) : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < kCombineBatch; u++) {
@@ -754,6 +762,8 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
             }
         }
         for (uint32_t ce = cbl; ce > c0; ce -= kCombineBatch) {                          // earlier batches: full, reloaded
+            // dark by the rule is dark for good: if the batch's first chunk is, all of it is the identity for this quadrant
+            if (reinterpret_cast<const uint8_t*>(chunk_dark + (ce - c0 >= (uint32_t)kCombineBatch ? ce - kCombineBatch : c0))[threadIdx.x >> 6] == 0x81) continue;
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
                 const uint32_t c = (ce - c0 > (uint32_t)u) ? ce - 1 - u : c0;
@@ -1089,11 +1099,13 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_kernel<false, true, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        tile_combine_kernel<false, true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     } else {
         if (max_chunks > 0) chunk_fwd_kernel<false, false, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        tile_combine_kernel<false, false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
@@ -1101,10 +1113,10 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
-            tile_combine_kernel<true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            tile_combine_kernel<true, true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         } else {
             chunk_fwd_kernel<true, false, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
-            tile_combine_kernel<true, false><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            tile_combine_kernel<true, false, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
         }
     }
     GSX_LAUNCH_CHECK();
