@@ -20,11 +20,11 @@ SYMBOLS = [
     "gsx_image_loss_workspace_bytes", "gsx_image_loss_fwd", "gsx_image_loss_bwd", "gsx_image_loss_fwd_grad",
     "gsx_l1_ssim_workspace_bytes", "gsx_l1_ssim_fwd", "gsx_l1_ssim_bwd",
     "gsx_keep_flags", "gsx_compact_rows", "gsx_clamp_inplace",
-    "gsx_merge_workspace_bytes", "gsx_merge_count", "gsx_merge_fill", "gsx_merge_greedy_host", "gsx_train_step",
+    "gsx_merge_workspace_bytes", "gsx_merge_count", "gsx_merge_fill", "gsx_merge_greedy_host", "gsx_train_step", "gsx_train_step_grads", "gsx_train_step_apply",
     "gsx_comm_available", "gsx_comm_unique_id", "gsx_comm_init", "gsx_allreduce_avg", "gsx_bcast", "gsx_comm_destroy",
 ]
 
-ABI_VERSION = 18            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 19            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE, GSX_E_AGAIN, GSX_E_COMM = 0, -1, -2, -3, -4, -5, -6
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -107,6 +107,8 @@ def lib():
     L.gsx_merge_fill.argtypes = [_p, _i32, C.c_float, _p, _p, _p, C.c_size_t, _p]
     L.gsx_merge_greedy_host.argtypes = [_i32, _p, _p, _p, _p, _p, _p]
     L.gsx_train_step.argtypes = [C.POINTER(GsxStep), _p]
+    L.gsx_train_step_grads.argtypes = [C.POINTER(GsxStep), _p]
+    L.gsx_train_step_apply.argtypes = [C.POINTER(GsxStep), _p]
     L.gsx_comm_unique_id.argtypes = [_p]
     L.gsx_comm_init.argtypes = [_i32, _i32, _p, C.POINTER(_p)]
     L.gsx_allreduce_avg.argtypes = [_p, _p, _i64, _p]

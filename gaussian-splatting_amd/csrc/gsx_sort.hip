@@ -308,6 +308,12 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     }
 }
 
+__global__ __launch_bounds__(kBlock) void iota_kernel(uint32_t* __restrict__ v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
 static size_t sort_ws_bytes(int64_t n)
 {
     int64_t nb = ceil_div(n > 0 ? n : 1, kSortTile);
@@ -337,6 +343,7 @@ int sort_pairs_internal(const uint32_t* k_in, const uint32_t* v_in, uint32_t* k_
     if (passes == 0) {   // nothing to sort on: copy through
         GSX_HIP(hipMemcpyAsync(k_a, k_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         if (v_in) GSX_HIP(hipMemcpyAsync(v_a, v_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        else iota_kernel<<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, st>>>(v_a, (uint32_t)n);     // "values_in == NULL means 0..n-1" holds here too
         if (check) {     // the check rides on a histogram launch
             radix_hist_kernel<<<dim3(nb), dim3(kBlock), 0, st>>>(k_in, n, n_dev, 0, 0u, hist, nb, check_bit);
             radix_rowscan_kernel<<<dim3(kRadix + 1), dim3(kBlock), 0, st>>>(hist, nb, totals, mismatch_dev);
@@ -391,6 +398,9 @@ GSX_API int gsx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* values_i
     }
     if (!keys_in || !keys_out || !values_out || !keys_tmp || !values_tmp || !ws) return GSX_E_INVALID;
     if (keys_in == keys_out || keys_in == keys_tmp || keys_out == keys_tmp) return GSX_E_INVALID;
+    // a pass that scatters from the buffer it scatters into corrupts the permutation silently
+    if (values_in && (values_in == values_out || values_in == values_tmp)) return GSX_E_INVALID;
+    if (values_out == values_tmp) return GSX_E_INVALID;
     return sort_pairs_internal(keys_in, values_in, keys_out, values_out, keys_tmp, values_tmp, n, nullptr, begin_bit, end_bit,
                                ws, ws_bytes, (hipStream_t)stream, check_bit, mismatch_dev);
 }
@@ -448,6 +458,7 @@ GSX_API int gsx_sort_pairs_u32_static(const uint32_t* keys_in, const uint32_t* v
     if (n > kStaticSortMaxN) return GSX_E_CAPACITY;            // beyond the static scratch: use gsx_sort_pairs_u32 with a workspace
     if (n == 0) return GSX_OK;
     if (!keys_in || !keys_out || !values_out || keys_in == keys_out) return GSX_E_INVALID;
+    if (values_in && values_in == values_out) return GSX_E_INVALID;      // with an odd pass count pass 0 would scatter in place
     void* base = nullptr;
     const int st = static_scratch(&base);
     if (st != GSX_OK) return st;

@@ -138,19 +138,33 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
 // clip + Adam, enqueued back to back.  The one place the host looks at the GPU is the count event, between the criterion
 // and the backward: the GPU is busy with the forward's second half meanwhile, and a step whose buffers were too small (or
 // whose depth sort was too narrow) reaches neither the backward nor the parameters.
-GSX_API int gsx_train_step(const gsx_step* s, void* stream)
+static int check_step(const gsx_step* s, bool grads, bool apply)
 {
-    if (!s || !s->pose || !s->target || !s->d_rgb || !s->loss || !s->loss_ws || !s->counts_pinned_host || !s->count_event) return GSX_E_INVALID;
-    if (s->step < 1 || s->loss_kind < GSX_LOSS_L1 || s->loss_kind > GSX_LOSS_L1_SSIM) return GSX_E_INVALID;
+    if (!s) return GSX_E_INVALID;
+    if (grads) {
+        if (!s->pose || !s->target || !s->d_rgb || !s->loss || !s->loss_ws || !s->counts_pinned_host || !s->count_event) return GSX_E_INVALID;
+        if (s->loss_kind < GSX_LOSS_L1 || s->loss_kind > GSX_LOSS_L1_SSIM) return GSX_E_INVALID;
+    }
+    if (apply && s->step < 1) return GSX_E_INVALID;
     uint32_t seen = 0;
     for (int k = 0; k < 5; k++) {
-        if (!s->param[k] || !s->grad[k] || !s->exp_avg[k] || !s->exp_avg_sq[k]) return GSX_E_INVALID;
+        if (!s->param[k] || !s->grad[k]) return GSX_E_INVALID;
+        if (apply && (!s->exp_avg[k] || !s->exp_avg_sq[k])) return GSX_E_INVALID;
         if (s->adam_order[k] < 0 || s->adam_order[k] > 4) return GSX_E_INVALID;
         seen |= 1u << s->adam_order[k];
     }
-    if (seen != 31u) return GSX_E_INVALID;
+    return seen == 31u ? GSX_OK : GSX_E_INVALID;
+}
+
+// The step in its two halves, for data-parallel ranks: everything up to the gradients (the flat buffer the caller hands
+// in through grad[]), then -- after the caller's one collective on the same stream -- clip + Adam.  gsx_train_step is
+// the two back to back.
+GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream)
+{
+    int st = check_step(s, true, false);
+    if (st != GSX_OK) return st;
     Layout L;
-    int st = make_layout(s->N, s->H, s->W, s->capacity, s->chunk_force, 1, L);
+    st = make_layout(s->N, s->H, s->W, s->capacity, s->chunk_force, 1, L);
     if (st != GSX_OK) return st;
     st = gsx_view_forward(s->param[0], s->param[1], s->param[2], s->param[3], s->param[4], s->pose, s->N, s->H, s->W, s->capacity,
                           s->depth_bits, nullptr, 1, s->chunk_force, s->arena, s->arena_bytes, s->mean2d, s->depth, s->cov2d,
@@ -184,7 +198,14 @@ GSX_API int gsx_train_step(const gsx_step* s, void* stream)
     st = gsx_preprocess_bwd(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
                             u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, nullptr, nullptr, nullptr, s->N, 0,
                             s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4], stream);
+    return st;
+}
+
+GSX_API int gsx_train_step_apply(const gsx_step* s, void* stream)
+{
+    const int st = check_step(s, false, true);
     if (st != GSX_OK) return st;
+    if (s->N <= 0) return GSX_E_INVALID;
     float* p[5]; float* g[5]; float* m[5]; float* v[5]; int64_t numel[5]; float lr[5];
     static const int64_t per_row[5] = {3, 3, 4, 1, 3};
     for (int k = 0; k < 5; k++) {
@@ -194,4 +215,13 @@ GSX_API int gsx_train_step(const gsx_step* s, void* stream)
     }
     return gsx_clip_adam_step(5, p, g, m, v, numel, lr, s->beta1, s->beta2, s->eps, s->step, s->max_grad_norm, s->write_clipped_grad,
                               s->adam_ws, s->adam_ws_bytes, stream);
+}
+
+GSX_API int gsx_train_step(const gsx_step* s, void* stream)
+{
+    int st = check_step(s, true, true);
+    if (st != GSX_OK) return st;
+    st = gsx_train_step_grads(s, stream);
+    if (st != GSX_OK) return st;
+    return gsx_train_step_apply(s, stream);
 }

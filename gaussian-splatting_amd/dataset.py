@@ -10,8 +10,9 @@ The interface kept from the reference is what its trainer consumes: `SceneDatase
 `len()`, and items `{'image': (3,H,W) float32 in [0,1], 'camera_pose': (4,4) float32, 'image_path': str}`, with the
 same exception types for a bad split, missing files and an image/pose count mismatch.  Everything else is this
 package's own: the scene is resolved once into a `SceneFiles` record, views can be fetched as raw uint8 (`view_u8`) so
-that the prefetcher moves one byte per channel over PCIe and scales on the GPU, and the metadata is exposed as the
-parsed JSON (`info`) rather than through helper methods.
+that the prefetcher moves one byte per channel over PCIe and scales on the GPU.  The reference class's other public
+members (`data_path`, `scene_info`, `image_paths`, `camera_poses`, `get_camera_intrinsics()`, `get_scene_bounds()`) are
+thin views of the same record, so code written against the reference's dataset keeps working.
 The reference decodes with OpenCV, which this image does not have; PIL decodes the same JPEG bytes, and the optional
 resize uses PIL's BOX filter where the reference uses cv2.INTER_AREA (both area averages; not bit-identical -- "parity
 unpinned" for the resize, no fixture of the reference covers it)."""
@@ -98,11 +99,46 @@ def write_scene(root, splits, metadata=None, quality=95) -> dict:
 
 class SceneDataset(Dataset):
     def __init__(self, data_path, split='train', transform=None, image_size=None):
+        from pathlib import Path
+        self.data_path = Path(data_path)
         self.files = resolve_scene(data_path, split)
         self.split, self.transform = split, transform
         self.image_size = None if image_size is None else (int(image_size[0]), int(image_size[1]))     # (W, H), as for cv2.resize
 
     info = property(lambda self: self.files.info)
+
+    # ---- the reference class's public surface over the same record (data_processing/dataset.py:34-47,168-216): code
+    # written against it reads these attributes and calls the two helpers ------------------------------------------
+    @property
+    def scene_info(self) -> dict:
+        return self.files.info
+
+    @property
+    def image_paths(self) -> list:
+        """sorted pathlib.Path objects, as `sorted(image_dir.glob('*.jpg'))` gives the reference"""
+        from pathlib import Path
+        return [Path(v) for v in self.files.views]
+
+    @property
+    def camera_poses(self) -> np.ndarray:
+        return self.files.poses
+
+    def get_camera_intrinsics(self) -> dict:
+        """focal_length, principal_point (cx, cy), image_size (W, H) from the metadata; when the metadata has no camera
+        block, the reference's fallback: max(H, W), the image centre and the size of the first view as loaded (:178-193)."""
+        try:
+            cam = self.files.info['metadata']['camera']
+            return {'focal_length': cam['focal_length'], 'principal_point': tuple(cam['principal_point']),
+                    'image_size': tuple(self.files.info['processing']['image_size'])}
+        except KeyError:
+            h, w = self.view_u8(0).shape[:2]
+            return {'focal_length': max(h, w), 'principal_point': (w / 2, h / 2), 'image_size': (w, h)}
+
+    def get_scene_bounds(self) -> dict:
+        """center (3,), extent (3,), aabb (2, 3) of the camera positions pose[:3, 3] (:195-216)."""
+        positions = self.files.poses[:, :3, 3]
+        lo, hi = positions.min(axis=0), positions.max(axis=0)
+        return {'center': (lo + hi) / 2, 'extent': hi - lo, 'aabb': np.stack([lo, hi])}
 
     def __len__(self):
         return len(self.files.views)

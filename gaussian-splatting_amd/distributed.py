@@ -47,7 +47,10 @@ def _adopt_strays(params, grads, tail):
             continue
         base = g.storage_offset() - o
         st = g.untyped_storage()
-        if base >= 0 and (base + need) * g.element_size() <= st.nbytes():
+        # only the render path's own buffer qualifies -- a storage of exactly 14 N + GRAD_TAIL floats with the gradients laid
+        # out from its start (render.RenderFunction.backward, trainer.FusedTrainStep): its tail is spare by construction.
+        # Gradients that merely sit somewhere inside a larger caller-owned storage keep what lies behind them (packed path).
+        if base == 0 and need * g.element_size() == st.nbytes():
             home = (st.data_ptr(), base, g)
             break
     if home is None:
@@ -167,6 +170,9 @@ def _flat_view_of(tensors, tail=0):
     off = (t0.data_ptr() - base) // t0.element_size()
     flat_all = torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage())
     if off + total + tail > flat_all.numel():
+        return None
+    # a tail is only spare in the render path's own buffer: exactly the gradients + GRAD_TAIL floats, from the storage's start
+    if tail and (off != 0 or flat_all.numel() != total + tail):
         return None
     return flat_all[off:off + total + tail]
 
@@ -346,8 +352,25 @@ class DataParallelSplat(torch.nn.Module):
                     dst.copy_(g.reshape(-1))
                 off += p.numel()
             self.last_sync_copied_bytes = total * flat.element_size()
-        flags = flat[total:total + FLAG_WORDS]
         pattern = tuple(1.0 if (i < k and grads[i] is not None) else 0.0 for i in range(FLAG_WORDS))
+        flags = self.exchange_flat(flat, total, pattern)
+        if packed or adopted:
+            # the averaged gradients stay where they are: .grad becomes a view of the exchange buffer (no copy back), and
+            # the five are consecutive again for whoever walks them next (clip_grad_norm_, the fused optimizer)
+            seen = flags.tolist() if any(g is None for g in grads) else None
+            off = 0
+            for i, p in enumerate(params):
+                if seen is None or seen[i] != 0.0:           # reached on some rank
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()                             # reached on no rank: grad stays None, like DDP
+
+    def exchange_flat(self, flat, total, pattern):
+        """The one collective of a data-parallel step on a buffer that is already flat: `total` gradient floats in
+        PARAM_ORDER followed by FLAG_WORDS presence flags (`pattern`, written here).  sync_gradients ends here, and the
+        one-call trainer step (trainer.FusedTrainStep) calls it between gsx_train_step_grads and gsx_train_step_apply on
+        the stream both are enqueued on.  Returns the flag words (a view of `flat`)."""
+        dev = flat.device
+        flags = flat[total:total + FLAG_WORDS]
         src = self._flag_cache.get((pattern, dev))
         if src is None:                                      # one host-to-device copy per pattern, not per step
             src = self._flag_cache[(pattern, dev)] = torch.tensor(pattern, dtype=flat.dtype).to(dev)
@@ -363,15 +386,11 @@ class DataParallelSplat(torch.nn.Module):
             ev[1].record()
             self.exchange_events.append(ev)
         self.last_allreduce_bytes = flat.numel() * flat.element_size()
-        if packed or adopted:
-            # the averaged gradients stay where they are: .grad becomes a view of the exchange buffer (no copy back), and
-            # the five are consecutive again for whoever walks them next (clip_grad_norm_, the fused optimizer)
-            seen = flags.tolist() if any(g is None for g in grads) else None
-            off = 0
-            for i, p in enumerate(params):
-                if seen is None or seen[i] != 0.0:           # reached on some rank
-                    p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()                             # reached on no rank: grad stays None, like DDP
+        return flags
+
+    def owns_hook(self, fn):
+        """is `fn` (an entry of a parameter's post-accumulate-grad hooks) this wrapper's own exchange trigger"""
+        return getattr(fn, "__self__", None) is self and getattr(fn, "__func__", None) is DataParallelSplat._on_grad
 
     def reduce_metrics(self, metrics, device=None):
         """trainer.py:228-233 for the plain-model branch: scalar entries averaged over the ranks, the rest passed through."""

@@ -249,20 +249,26 @@ class GaussianSplat(nn.Module):
             sel = jj >= ii         # torch.triu keeps the diagonal: a self-distance that rounds above 0 "merges" i with itself (and removes it), as in the reference
             pairs.append(torch.stack([ii[sel], jj[sel]], 1).cpu())
         pairs = torch.cat(pairs) if pairs else torch.zeros(0, 2, dtype=torch.long)
-        merged = set()
-        for i, j in pairs.tolist():
-            if i in merged or j in merged:
-                continue
-            w1, w2 = self.opacity.data[i], self.opacity.data[j]
-            total_weight = w1 + w2
-            self.positions.data[i] = (w1 * self.positions.data[i] + w2 * self.positions.data[j]) / total_weight
-            self.features.data[i] = (w1 * self.features.data[i] + w2 * self.features.data[j]) / total_weight
-            self.opacity.data[i] = torch.maximum(w1, w2)
-            merged.add(j)
-        if merged:
-            keep = torch.ones(n, dtype=torch.bool, device=pos0.device)
-            keep[list(merged)] = False
-            self._replace_parameters([p.data[keep] for p in (self.positions, self.scales, self.rotations, self.opacity, self.features)])
+        if pairs.shape[0] == 0:
+            return
+        # the order-dependent walk over the pair list is the library's host routine (the one the GPU path uses): the list
+        # as CSR rows (row-major order == ascending i, then j), host copies of the three tensors it rewrites
+        import ctypes as C
+        from . import _lib as L
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        row_start = torch.zeros(n + 1, dtype=torch.int32)
+        row_start[1:] = torch.cumsum(torch.bincount(pairs[:, 0], minlength=n), 0).to(torch.int32)
+        partners = pairs[:, 1].to(torch.int32).contiguous()
+        host = [t.data.float().cpu().contiguous().clone() for t in (self.positions, self.features, self.opacity)]
+        removed = torch.empty(n, dtype=torch.uint8)
+        L.check(L.lib().gsx_merge_greedy_host(n, ptr(row_start), ptr(partners), ptr(host[0]), ptr(host[1]), ptr(host[2]), ptr(removed)),
+                "gsx_merge_greedy_host")
+        keep = removed == 0
+        if bool(keep.all()):
+            kept = [host[0], self.scales.data, self.rotations.data, host[2], host[1]]
+        else:
+            kept = [host[0][keep], self.scales.data[keep], self.rotations.data[keep], host[2][keep], host[1][keep]]
+        self._replace_parameters([t.to(pos0.device) for t in kept])
 
     def _merge_pairs_hip(self, threshold: float):
         """(offsets (N+1,) int64 host, partners (P,) int32 host): i's partners j > i, ascending, for every i."""

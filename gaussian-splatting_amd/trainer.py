@@ -102,10 +102,13 @@ class FusedTrainStep:
     modular backward; the optimizer's state (exp_avg, exp_avg_sq, step counts) is the FusedClipAdam's own, so
     checkpoints and a later optimizer.step() see nothing unusual.  train_step() routes here by itself."""
 
-    def __init__(self, model, optimizer, kind, lambda_dssim):
+    def __init__(self, model, optimizer, kind, lambda_dssim, dp=None):
         from . import _lib as L, render as R
         self.L, self.R = L, R
         self.model, self.optimizer, self.kind = model, optimizer, kind
+        # a data-parallel wrapper around `model` (distributed.DataParallelSplat), or None: with one, the step runs as its two
+        # halves (gsx_train_step_grads, gsx_train_step_apply) with the wrapper's one collective over `flat` between them
+        self.dp = dp
         self.params = [model.positions, model.scales, model.rotations, model.opacity, model.features]
         n = self.n = self.params[0].shape[0]
         dev = self.dev = self.params[0].device
@@ -121,10 +124,6 @@ class FusedTrainStep:
         order = sorted(range(5), key=lambda t: group_of[id(self.params[t])])                # the order optimizer.step() walks them in
         for k in range(5):
             S.param[k] = self.params[k].data_ptr(); S.grad[k] = self.grads[k].data_ptr(); S.adam_order[k] = order[k]
-        S.beta1, S.beta2 = optimizer.param_groups[0]['betas']
-        S.eps = optimizer.param_groups[0]['eps']
-        S.max_grad_norm = optimizer.max_grad_norm
-        S.write_clipped_grad = 1 if optimizer.write_clipped_grad else 0
         S.N = n
         S.loss_kind, S.lambda_dssim = kind, lambda_dssim
         self.group_of = group_of
@@ -142,7 +141,11 @@ class FusedTrainStep:
         wsb = lib.gsx_l1_ssim_workspace_bytes(3, H, W) if self.kind == 2 else lib.gsx_image_loss_workspace_bytes()
         self.loss_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         S.H, S.W = H, W
-        S.mean2d = S.depth = S.cov2d = None           # the criterion looks at the image only: the projection keeps its 28 B per Gaussian of returned tensors to itself
+        # the reference's forward returns these per-Gaussian tensors ('positions', 'depths', 'scales', gaussian_splatting.py:212-219)
+        # whatever the criterion looks at: the step writes them too (28 B per Gaussian; `outputs` hands them out)
+        self.mean2d = torch.empty(1, n, 2, dtype=f32, device=dev); self.depth = torch.empty(1, n, dtype=f32, device=dev)
+        self.cov2d = torch.empty(1, n, 2, 2, dtype=f32, device=dev)
+        S.mean2d, S.depth, S.cov2d = self.mean2d.data_ptr(), self.depth.data_ptr(), self.cov2d.data_ptr()
         S.rgb, S.alpha, S.d_rgb, S.state = self.rgb.data_ptr(), self.alpha.data_ptr(), self.d_rgb.data_ptr(), self.state.data_ptr()
         S.loss_ws, S.loss_ws_bytes = self.loss_ws.data_ptr(), wsb
         self.cap = -1
@@ -162,6 +165,12 @@ class FusedTrainStep:
         H, W = int(target.shape[-2]), int(target.shape[-1])
         if self.shape != (H, W):
             self._bind_image(H, W)
+        # what optimizer.step() would read this step (a caller may edit param_groups or max_grad_norm between steps)
+        g0 = opt.param_groups[0]
+        S.beta1, S.beta2 = g0['betas']
+        S.eps = g0['eps']
+        S.max_grad_norm = opt.max_grad_norm
+        S.write_clipped_grad = 1 if opt.write_clipped_grad else 0
         # the optimizer's own bookkeeping (FusedClipAdam.step): state on first use, one step count for all five
         step = None
         for k, p in enumerate(self.params):
@@ -196,7 +205,7 @@ class FusedTrainStep:
                 if cap != self.cap or S.chunk_force != R._scratch.force_chunk:
                     self._bind_capacity(cap)
                 S.depth_bits = R._scratch.depth_bits.get(dev, 32)
-                status = lib.gsx_train_step(C.byref(S), stream)
+                status = (lib.gsx_train_step if self.dp is None else lib.gsx_train_step_grads)(C.byref(S), stream)
                 if status == L.GSX_E_CAPACITY and int(pinned[0]) > cap:   # nothing was applied: grow the block, same step again
                     R._scratch.grow(dev, int(pinned[0]))
                     continue
@@ -205,6 +214,12 @@ class FusedTrainStep:
                     continue
                 L.check(status, "gsx_train_step")
                 break
+            if self.dp is not None:
+                # the exchange (DDP's gradient average, scripts/train.py:134-139) between backward and clip + Adam, on the
+                # stream both halves are enqueued on: the render buffer as it is, presence flags behind the gradients
+                self.dp.last_sync_was_flat, self.dp.last_sync_copied_bytes = True, 0
+                self.dp.exchange_flat(self.flat[:14 * self.n + _FLAG_WORDS], 14 * self.n, _ALL_FIVE)
+                L.check(lib.gsx_train_step_apply(C.byref(S), L.stream_ptr(dev)), "gsx_train_step_apply")
         R._scratch.depth_bits[dev] = R.DEPTH_CHECK_BIT if int(pinned[1]) == 0 else 32
         R._last_D = int(pinned[0])
         for p, g in zip(self.params, self.grads):
@@ -215,6 +230,12 @@ class FusedTrainStep:
         self.model._last_state = self.state[0:1]
         return loss[0]
 
+    def outputs(self):
+        """The last step's forward outputs under the reference's keys (gaussian_splatting.py:212-219), as views of this
+        object's buffers (overwritten by the next step)."""
+        return {'rendered_images': self.rgb.unsqueeze(0), 'positions': self.mean2d, 'depths': self.depth, 'scales': self.cov2d,
+                'features': self.model.features, 'opacity': self.model.opacity, 'alpha': self.alpha.unsqueeze(0)}
+
 
 def _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_norm):
     """The FusedTrainStep that can stand in for this call of train_step, or None.  Cheap: runs every step."""
@@ -223,7 +244,15 @@ def _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_no
         return None
     from .model import GaussianSplat
     from .optim import FusedClipAdam
+    from .distributed import DataParallelSplat
     from . import render as R
+    dp = None
+    if isinstance(model, DataParallelSplat):          # the wrapper (either face): the step runs as its two halves around the exchange
+        dp, model = model, model.module
+        if not dp.active:
+            dp = None                                 # world 1 without forced collectives: no hooks, nothing to exchange
+        elif not dp._sync_enabled:
+            return None                               # inside no_sync(): gradients accumulate, which the one-call step does not do
     if type(optimizer) is not FusedClipAdam or not isinstance(model, GaussianSplat) or R._timer is not None or R.STAGED:
         return None
     if float(optimizer.max_grad_norm) != float(max_grad_norm) or getattr(model, "render_depth_map", False):
@@ -235,24 +264,31 @@ def _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_no
             or tuple(target.shape[:-2]) not in ((1, 3), (3,)) or pos.shape[0] == 0):
         return None
     params = [model.positions, model.scales, model.rotations, model.opacity, model.features]
-    for p in params:                  # hooks (a data-parallel wrapper's, a user's) only fire on the autograd path
+    for p in params:                  # a user's hooks only fire on the autograd path; the wrapper's own are what `dp` replaces
         if (p.dtype != torch.float32 or not p.is_contiguous() or not p.requires_grad or p.device != dev
-                or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None)):
+                or getattr(p, "_backward_hooks", None)):
             return None
+        hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+        if hooks and not (dp is not None and all(dp.owns_hook(fn) for fn in hooks.values())):
+            return None
+    if dp is not None and len(dp._dp_params()) != 5:
+        return None
     hit = getattr(optimizer, "_fused_step", None)
-    if hit is not None and hit.model is model and hit.kind == spec[0] and all(a is b for a, b in zip(hit.params, params)):
+    if (hit is not None and hit.model is model and hit.dp is dp and hit.kind == spec[0] and hit.n == pos.shape[0]
+            and all(a is b for a, b in zip(hit.params, params))):
         return hit
     grouped = [p for g in optimizer.param_groups for p in g['params']]
     if len(grouped) != 5 or {id(p) for p in grouped} != {id(p) for p in params}:
         return None
-    optimizer._fused_step = hit = FusedTrainStep(model, optimizer, spec[0], spec[1])
+    optimizer._fused_step = hit = FusedTrainStep(model, optimizer, spec[0], spec[1], dp)
     return hit
 
 
 def train_step(model, optimizer, camera_poses, target, loss_fn=l1_loss, max_grad_norm=0.1):
     """One step (trainer.py:134-175).  With a DataParallelSplat model the gradient all-reduce
-    fires inside backward(); clipping then sees the averaged gradients, like DDP.  The plain single-view case (bare model,
-    FusedClipAdam, l1_loss / l1_ssim_loss / clamped_mse_loss) runs as one library call (FusedTrainStep): same bits."""
+    fires inside backward(); clipping then sees the averaged gradients, like DDP.  The plain single-view case (a
+    GaussianSplat, bare or inside a DataParallelSplat, FusedClipAdam, l1_loss / l1_ssim_loss / clamped_mse_loss) runs
+    through the library's one-call step (FusedTrainStep; in two halves around the exchange when data-parallel): same bits."""
     fused_step = _fused_step_for(model, optimizer, camera_poses, target, loss_fn, max_grad_norm)
     if fused_step is not None:
         return fused_step(camera_poses, target)
@@ -325,11 +361,20 @@ def save_checkpoint(path, model, optimizer, epoch, loss, scheduler=None, **extra
 
 
 def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location=None):
-    """Restores what save_checkpoint (or the reference's trainer, minus its pickled config: weights_only=True refuses
-    that key's class, by design) wrote and returns the epoch to resume from, like trainer.py:273-295.  Keys saved from
-    inside a DistributedDataParallel ('module.' prefix) are accepted; a Gaussian count other than the model's raises, as
-    load_state_dict does (GaussianSplat.load_state is the call that resizes)."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    """Restores what save_checkpoint wrote and returns the epoch to resume from, like trainer.py:273-295.  Keys saved
+    from inside a DistributedDataParallel ('module.' prefix) are accepted; a Gaussian count other than the model's raises,
+    as load_state_dict does (GaussianSplat.load_state is the call that resizes).
+    A file written by the REFERENCE's trainer cannot be read as it is: it pickles its OmegaConf config object into the
+    dict (trainer.py:257), and this loader executes nothing from the file (weights_only=True), so the whole file is
+    refused -- with an error that says so.  Re-save it on the reference side without the 'config' key."""
+    import pickle
+    try:
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise RuntimeError(
+            f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0][:160]}).  Checkpoints of the reference's "
+            "trainer hold a pickled config object under 'config' (training/trainer.py:257); this loader executes nothing "
+            "from the file.  Re-save the checkpoint without that key (tensors and plain values only) and load it again.") from e
     inner = model.module if hasattr(model, "module") else model
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt['model_state_dict'].items()}
     inner.load_state_dict(sd)
@@ -340,4 +385,6 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location=No
     return int(ckpt['epoch']) + 1
 
 
+_FLAG_WORDS = 8                                   # distributed.FLAG_WORDS == render.GRAD_TAIL
+_ALL_FIVE = (1.0,) * 5 + (0.0,) * 3               # presence flags of a backward that reached all five tensors
 _FUSED_LOSSES.update({l1_loss: (0, 0.0), clamped_mse_loss: (1, 0.0), l1_ssim_loss: (2, 0.2)})

@@ -7,15 +7,20 @@
  * reference lines whose work it replaces.  The Python side that binds these with ctypes is
  * gaussian-splatting_amd/_lib.py; INTEGRATION.md shows the stub a maintainer of the reference adds.
  *
- * Conventions (all entry points):
+ * Conventions (all entry points unless an entry point's own comment says otherwise):
  *   - extern "C", plain pointers and sizes, no torch types; return 0 (GSX_OK) or a negative GSX_E_*.
  *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in _host;
  *     nothing here allocates or frees device memory.
- *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous; only
- *     gsx_bin_instances synchronises the stream once (8-byte read-back of the instance count).
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous.  Three entry points make the HOST
+ *     wait: gsx_bin_instances synchronises the stream once (8-byte read-back of the instance count); gsx_train_step and
+ *     gsx_train_step_grads block on the caller's count_event (recorded in the middle of the view's forward: the host
+ *     learns the instance count while the GPU composites) before they enqueue the backward; the gsx_comm_* calls are
+ *     RCCL's and block as RCCL does (gsx_comm_init until every rank has joined).
  *   - fp32 arithmetic; integer products (sort keys, tile rectangles, tile ranges) are bit-exact
  *     against oracle/gsx_oracle.c.
- *   - re-entrant; no global state.  One host thread per stream.
+ *   - re-entrant, one host thread per stream.  Global state, all of it: the thread-local last HIP error
+ *     (gsx_last_hip_error), the handle of librccl once gsx_comm_* has opened it, and the device array of
+ *     gsx_sort_pairs_u32_static with its per-device address table (calls of THAT entry point that overlap on one GPU race).
  */
 #ifndef GSX_H
 #define GSX_H
@@ -39,7 +44,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 18
+#define GSX_ABI_VERSION 19
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -294,7 +299,14 @@ int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int3
  * depth_bits < 32 with a non-zero mismatch count returns GSX_E_AGAIN (retry with depth_bits = 32) -- in both cases
  * neither the backward nor the optimizer was enqueued: gradients, parameters and Adam state are untouched (rgb and *loss
  * are those of the truncated / mis-sorted view); the caller grows the block / widens the sort and calls again with the
- * same `step`.  GSX_OK: the step is enqueued whole. */
+ * same `step`.  GSX_OK: the step is enqueued whole.
+ * gsx_train_step_grads / gsx_train_step_apply are the step's two halves, for data-parallel ranks (the reference wraps the
+ * model in DistributedDataParallel, scripts/train.py:134-139: the gradient average sits between backward and
+ * clip_grad_norm_, training/trainer.py:166-175): _grads enqueues everything up to the gradients (forward, criterion,
+ * the count check described above, both backward stages) and leaves them in grad[] -- five views of ONE flat buffer when
+ * the caller lays them out that way -- and _apply enqueues gsx_clip_adam_step; the caller issues its one collective over
+ * the gradient buffer on the same stream between the two.  _grads ignores the Adam fields (exp_avg, exp_avg_sq, lr,
+ * betas, step), _apply reads only those, param, grad, adam_order, N and the workspace.  gsx_train_step == _grads; _apply. */
 #define GSX_LOSS_L1_SSIM 2
 typedef struct gsx_step {
     float* param[5];               /* updated in place */
@@ -326,6 +338,8 @@ typedef struct gsx_step {
     void* count_event;             /* hipEvent_t */
 } gsx_step;
 int gsx_train_step(const gsx_step* s, void* stream);
+int gsx_train_step_grads(const gsx_step* s, void* stream);
+int gsx_train_step_apply(const gsx_step* s, void* stream);
 
 /* ---- the gradient exchange for hosts without torch.distributed: RCCL behind five calls.  Replaces what the
  * reference gets from dist.init_process_group("nccl") + DistributedDataParallel (scripts/train.py:65-73,134-139: the

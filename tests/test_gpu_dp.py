@@ -58,6 +58,46 @@ dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
+_STEP_WORKER = _COMMON + r'''
+# the one-call trainer step in its two halves around the exchange (gsx_train_step_grads -> collective -> gsx_train_step_apply)
+# against the modular data-parallel step (module forward, autograd, hooks, optimizer.step()): same kernels, same collective
+import gaussian_splatting_amd.trainer as T
+from gaussian_splatting_amd.distributed import ddp_compatible
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+target = torch.rand(1, 3, H, W, generator=gen).to(dev)
+def run(fused, wrap):
+    T.FUSED_STEP = fused
+    m = fresh(); dp = wrap(m)
+    opt = T.make_optimizer(dp, fused_clip_norm=0.1)
+    losses = []
+    for s in range(3):
+        v = (2 * s + rank) % 8
+        losses.append(float(T.train_step(dp, opt, poses[v:v + 1], target, T.l1_loss, max_grad_norm=0.1)))
+    torch.cuda.synchronize()
+    drv = getattr(opt, "_fused_step", None)
+    assert (drv is not None and drv.dp is dp) == fused, (fused, drv)
+    assert dp.last_sync_was_flat and dp.last_allreduce_bytes == (14 * N + 8) * 4
+    return m, opt, losses
+ma, oa, la = run(False, DataParallelSplat)
+for wrap in (DataParallelSplat, ddp_compatible):
+    mb, ob, lb = run(True, wrap)
+    assert la == lb, (la, lb)
+    for k in PARAM_ORDER:
+        assert torch.equal(getattr(ma, k), getattr(mb, k)), (k, float((getattr(ma, k) - getattr(mb, k)).abs().max()))
+        assert torch.equal(getattr(ma, k).grad, getattr(mb, k).grad), k
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa.state[getattr(ma, k)][key], ob.state[getattr(mb, k)][key]), (k, key)
+T.FUSED_STEP = True
+# both ranks must hold the same parameters (replicas must not drift)
+flat = torch.cat([getattr(mb, k).detach().reshape(-1) for k in PARAM_ORDER]).cpu()
+both = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1])
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
 _RCCL_WORKER = _COMMON + r'''
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -82,6 +122,21 @@ def test_two_ranks_average_real_render_gradients(tmp_path):
     script = tmp_path / "dp_gpu_worker.py"
     script.write_text(_GLOO_WORKER)
     port = "29671"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_one_call_step_between_exchange_equals_modular_dp_step(tmp_path):
+    """data-parallel ranks take the one-call step too (reference: training/trainer.py:133-175 under the DDP
+    wrap of scripts/train.py:134-139).  Two gloo ranks on the one GPU, three trainer steps each way: losses, parameters,
+    gradients and Adam moments bit-equal, replicas equal across the ranks."""
+    script = tmp_path / "dp_step_worker.py"
+    script.write_text(_STEP_WORKER)
+    port = "29675"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],

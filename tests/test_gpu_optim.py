@@ -370,6 +370,51 @@ def test_fused_train_step_declines_what_it_cannot_do():
     assert torch.isfinite(loss) and m.positions.grad is not None and opt._fused_step is not None
 
 
+def test_fused_step_writes_the_reference_forward_outputs():
+    """The one-call step must produce what GaussianSplat.forward returns (gaussian_splatting.py:212-219), the per-Gaussian
+    'positions' / 'depths' / 'scales' included (the timed step used to leave them out), and it follows
+    the optimizer's hyper-parameters from step to step (betas / eps / clip norm were frozen at construction)."""
+    from gaussian_splatting_amd import GaussianSplat, trainer as T
+    from gaussian_splatting_amd.scenes import create_orbit_poses
+    dev = torch.device("cuda:0")
+    H, W, n = 64, 96, 4000
+    poses = torch.from_numpy(create_orbit_poses(4.0, 60, 45.0)).to(dev)
+    target = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+    torch.manual_seed(6)
+    m = GaussianSplat(n)
+    with torch.no_grad():
+        m.positions[:, 2] = m.positions[:, 2].abs() * 0.8 + 0.2
+    m = m.to(dev)
+    opt = T.make_optimizer(m, fused_clip_norm=0.1)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in m(poses[4:5], (H, W)).items()}
+    T.train_step(m, opt, poses[4:5], target, T.l1_loss, 0.1)
+    got = opt._fused_step.outputs()
+    for k in ("rendered_images", "positions", "depths", "scales", "alpha"):
+        assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), k
+    # edited hyper-parameters reach the next step: the twin runs the modular path with the same edits
+    torch.manual_seed(6)
+    m2 = GaussianSplat(n)
+    with torch.no_grad():
+        m2.positions[:, 2] = m2.positions[:, 2].abs() * 0.8 + 0.2
+    m2 = m2.to(dev)
+    opt2 = T.make_optimizer(m2, fused_clip_norm=0.1)
+    T.FUSED_STEP = False
+    try:
+        T.train_step(m2, opt2, poses[4:5], target, T.l1_loss, 0.1)
+        for o in (opt, opt2):
+            o.max_grad_norm = 0.05
+            for g in o.param_groups:
+                g['betas'] = (0.8, 0.99); g['eps'] = 1e-6
+        T.train_step(m2, opt2, poses[9:10], target, T.l1_loss, 0.05)
+    finally:
+        T.FUSED_STEP = True
+    T.train_step(m, opt, poses[9:10], target, T.l1_loss, 0.05)
+    assert opt._fused_step is not None and getattr(opt2, "_fused_step", None) is None
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+
+
 def test_flat_parameters_under_the_fused_step():
     """Parameters re-seated into one buffer (GaussianSplat.flatten_parameters) in the MIDDLE of training: the
     one-call step picks the new addresses up, and the run stays bit-equal to one whose parameters never moved."""

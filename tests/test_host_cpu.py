@@ -1,6 +1,7 @@
 """CPU tier: host logic that needs no GPU -- the C-ABI library loads and exports every symbol
 include/gsx.h declares, the drop-in module mirrors the reference's interface, the orbit camera
 path, the trainer's optimizer groups, and the data-parallel gradient exchange (gloo, world 2)."""
+import json
 import os
 import re
 import subprocess
@@ -315,6 +316,71 @@ def test_scene_dataset_follows_reference_format(tmp_path):
     assert len(got) == 2 and got[0][0].shape == (1, 3, 12, 16) and got[0][1].shape == (1, 4, 4) and got[1][2].endswith("0000.jpg")
 
 
+def test_scene_reader_on_a_foreign_scene_decode_resize_parity_unpinned(tmp_path):
+    """the reader on a scene this package's writer did NOT make (tests/golden/scene_n2, bytes
+    committed, built by tests/golden/make_scene_n2.py): odd sizes, a grayscale JPEG, a progressive one, names whose string
+    order differs from their numeric order, a stray .txt, a .png and a sub-directory in the split folder, float64 poses,
+    no camera block in the metadata.  Asserted: item shapes / dtypes / order and the documented exceptions of
+    /root/reference/data_processing/dataset.py:35-54,106-120, plus the reference class's public members.
+    NOT asserted: decoded pixel values against the reference -- it decodes with OpenCV (absent here) and holds no decoded
+    fixture: decode / resize parity is UNPINNED; the content is only bounded against the rasters the JPEGs were made from."""
+    import shutil
+    from pathlib import Path
+    from gaussian_splatting_amd.dataset import SceneDataset
+    src = os.path.join(ROOT, "tests", "golden", "scene_n2")
+    rasters = np.load(os.path.join(src, "rasters.npz"))
+    ds = SceneDataset(src, "train")
+    assert len(ds) == 4                                               # the .txt, the .png and thumbs/t.jpg are not views
+    names = [os.path.basename(ds[i]["image_path"]) for i in range(4)]
+    assert names == ["view_10.jpg", "view_2.jpg", "view_3.jpg", "view_a.jpg"]          # sorted() of the paths, as the reference's glob
+    poses = np.load(os.path.join(src, "poses", "train_poses.npy"))
+    assert poses.dtype == np.float64
+    for i in range(4):
+        it = ds[i]
+        assert it["image"].shape == (3, 11, 17) and it["image"].dtype == torch.float32          # grayscale file -> 3 equal planes (cv2.imread's default)
+        assert it["camera_pose"].shape == (4, 4) and it["camera_pose"].dtype == torch.float32
+        assert np.array_equal(it["camera_pose"].numpy(), poses[i].astype(np.float32))           # pose i belongs to the i-th NAME
+        assert isinstance(it["image_path"], str)
+        want = rasters["train__" + names[i]].astype(np.float32)
+        want = np.repeat(want[..., None], 3, -1) if want.ndim == 2 else want
+        assert np.abs(it["image"].permute(1, 2, 0).numpy() * 255.0 - want).mean() < 6.0, names[i]
+    g = ds[1]["image"]
+    assert torch.equal(g[0], g[1]) and torch.equal(g[1], g[2])
+    v = SceneDataset(src, "val")
+    assert len(v) == 1 and v[0]["image"].shape == (3, 13, 9)
+    assert SceneDataset(src, "val", image_size=(5, 7))[0]["image"].shape == (3, 7, 5)           # (W, H)
+    # the reference class's public surface (data_processing/dataset.py:34-47,168-216)
+    assert ds.data_path == Path(src) and ds.scene_info["metadata"]["scene_name"] == "n2_fixture"
+    assert all(isinstance(p, Path) for p in ds.image_paths) and [p.name for p in ds.image_paths] == names
+    assert ds.camera_poses.shape == (4, 4, 4)
+    assert ds.get_camera_intrinsics() == {"focal_length": 17, "principal_point": (8.5, 5.5), "image_size": (17, 11)}     # no camera block: the fallback
+    b = ds.get_scene_bounds()
+    pos = poses[:, :3, 3].astype(np.float32)
+    assert np.allclose(b["aabb"], np.stack([pos.min(0), pos.max(0)])) and np.allclose(b["center"], (pos.min(0) + pos.max(0)) / 2)
+    assert np.allclose(b["extent"], pos.max(0) - pos.min(0)) and b["aabb"].shape == (2, 3)
+    # a camera block in the metadata is returned as it is
+    work = tmp_path / "scene"
+    shutil.copytree(src, work)
+    info = json.load(open(work / "metadata" / "scene_info.json"))
+    info["metadata"]["camera"] = {"focal_length": 20.5, "principal_point": [8.0, 5.0]}
+    json.dump(info, open(work / "metadata" / "scene_info.json", "w"))
+    assert SceneDataset(work, "train").get_camera_intrinsics() == {"focal_length": 20.5, "principal_point": (8.0, 5.0), "image_size": (17, 11)}
+    # the documented exceptions
+    with pytest.raises(ValueError):
+        SceneDataset(src, "holdout")                                  # :35-36
+    with pytest.raises(FileNotFoundError):
+        SceneDataset(src, "test")                                     # :108-110 no image directory / :116-118 no pose file
+    os.remove(work / "images" / "train" / "view_a.jpg")
+    with pytest.raises(ValueError):
+        SceneDataset(work, "train")                                   # :50-54 3 images, 4 poses
+    (work / "images" / "val" / "0.jpg").write_bytes(b"not a jpeg")
+    with pytest.raises(ValueError):
+        SceneDataset(work, "val")[0]                                  # :136-138 undecodable view
+    os.remove(work / "metadata" / "scene_info.json")
+    with pytest.raises(FileNotFoundError):
+        SceneDataset(work, "val")                                     # :99-101
+
+
 def test_write_scene_round_trips_through_the_reader(tmp_path):
     """The writer side of the N2 format (data_processing/preprocessor.py:177-220,241-247,262-293): directories, file
     names, pose file, scene_info.json keys; what it writes is what SceneDataset reads."""
@@ -369,6 +435,12 @@ def test_checkpoint_file_has_the_reference_layout(tmp_path):
     assert T.load_checkpoint(path, m3) == 4 and torch.equal(m3.positions, m.positions)
     with pytest.raises(RuntimeError):
         T.load_checkpoint(path, GaussianSplat(41))
+    # a file of the reference's trainer holds a pickled config object (trainer.py:257): refused whole, with an error that says why
+    import argparse
+    raw["config"] = argparse.Namespace(model={"num_gaussians": 40})
+    torch.save(raw, path)
+    with pytest.raises(RuntimeError, match="pickled config"):
+        T.load_checkpoint(path, GaussianSplat(40))
 
 
 def test_step_struct_layout_matches_header(tmp_path):

@@ -60,3 +60,13 @@ def test_static_scratch_sort_equals_workspace_sort():
         assert st == L.GSX_E_CAPACITY and b"too small" in lib.gsx_strerror(st)
         assert lib.gsx_sort_pairs_u32_static(big.data_ptr(), None, big.data_ptr(), out_v.data_ptr(), 16, 0, 32, L.stream_ptr(dev)) == L.GSX_E_INVALID
         assert lib.gsx_sort_pairs_u32_static(None, None, None, None, 0, 0, 32, L.stream_ptr(dev)) == L.GSX_OK       # empty: nothing to do
+        # values sorted in place: with an odd pass count pass 0 would scatter from the buffer it scatters into -- refused
+        k16 = torch.arange(16, dtype=torch.int32, device=dev); v16 = torch.arange(16, dtype=torch.int32, device=dev)
+        assert lib.gsx_sort_pairs_u32_static(k16.data_ptr(), v16.data_ptr(), out_k.data_ptr(), v16.data_ptr(), 16, 8, 16, L.stream_ptr(dev)) == L.GSX_E_INVALID
+        # an empty bit range copies through, and implicit values are still 0..n-1 as the header promises
+        n0 = 1000
+        k0 = torch.randint(0, 1 << 20, (n0,), generator=g, dtype=torch.int64).to(torch.int32).to(dev)
+        ko = torch.full_like(k0, -1); vo = torch.full((n0,), -1, dtype=torch.int32, device=dev)
+        L.check(lib.gsx_sort_pairs_u32_static(k0.data_ptr(), None, ko.data_ptr(), vo.data_ptr(), n0, 12, 12, L.stream_ptr(dev)), "static, no bits")
+        torch.cuda.synchronize()
+        assert torch.equal(ko, k0) and torch.equal(vo, torch.arange(n0, dtype=torch.int32, device=dev))
