@@ -788,11 +788,22 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// F3: exact global early-exit index (gaussian_splatting.py:147).  Runs only when F2 found every
-// pixel saturated.  One workgroup per tile walks the list with the REFERENCE's arithmetic
-// (A += (1-A)*alpha, :144) and records, per pixel, the first rank after which A > 0.99; the
-// global maximum is the exit index.  A tile stops as soon as all its pixels have saturated.
+// F3: exact global early-exit index (gaussian_splatting.py:147): the first rank k* after which EVERY pixel's accumulated
+// alpha is > 0.99 at once.  Runs only when F2 found every pixel saturated at the end of its list.  Workgroups walk the tile
+// lists with the REFERENCE's arithmetic (A += (1-A)*alpha, :144).
+// With every alpha in [0, 1] a pixel's A only grows, and k* is the maximum over the pixels of the first rank after which
+// A > 0.99.  An opacity outside [0, 1] lets A overshoot and come back under the threshold (training pushes raw opacities
+// past 1; with opacities in (1, 3] the first-crossing rule was off on most scenes: tests/golden exitop*), so the search is
+// the fixpoint of
+//     k <- max over pixels p of f_p(k),   f_p(k) = the first rank k' >= k at which p is saturated
+// ("at k'": after the last instance of p's tile with rank <= k').  k never decreases, never passes k* (at k* every pixel is
+// saturated, so f_p(k) <= k* for k <= k*), and a fixpoint is a rank at which all pixels are saturated: it is k*.  One pass
+// over the lists per round, a grid barrier between rounds (the grid is at most kSatBlocks workgroups, all resident; every
+// workgroup arrives at every barrier, and the rounds end because k grows until it stands or some pixel reports "never");
+// the monotone case takes two rounds (the second confirms).  state[2] = the running maximum (monotone: no reset between
+// rounds), state[3] = barrier arrivals; both zeroed with state[0..1] by pass 0.
 // ------------------------------------------------------------------------------------------
+constexpr int kSatBlocks = 256;
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state)
@@ -800,45 +811,69 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
     __shared__ uint32_t s_red[4];
-    if (state[1] != 0u) {                    // some pixel never saturates: no early exit
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(state, GSX_RANK_NONE);
+    __shared__ uint32_t s_k;
+    if (state[1] != 0u) {                    // some pixel never saturates: no early exit (uniform over the grid: written by pass 0)
+        if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = GSX_RANK_NONE;
         return;
     }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {     // small grid: this launch is a no-op on unsaturated views
-    const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
-    const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
-    const bool inside = x < W && y < H;
-    const float gx = pix_coord(min(x, W - 1), W, stepx), gy = pix_coord(min(y, H - 1), H, stepy);
-    float A = 0.f;
-    uint32_t sat = inside ? GSX_RANK_NONE : 0u;        // pixels outside the image do not vote
-    for (uint32_t start = begin; start < end; start += kBlock) {
-        const uint32_t i = start + threadIdx.x;
-        if (i < end) {
-            const uint32_t r = ranks[i];
-            s_rank[threadIdx.x] = r;
-            const float4* R = rec + (size_t)3 * r;
-            s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1];
+    uint32_t k_cur = 0u, result;
+    for (uint32_t round = 1u; ; round++) {
+        uint32_t mine = 0u;                  // max of f_p(k_cur) over this thread's pixels (GSX_RANK_NONE = never: the largest value)
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
+            const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
+            const bool inside = x < W && y < H;
+            const float gx = pix_coord(min(x, W - 1), W, stepx), gy = pix_coord(min(y, H - 1), H, stepy);
+            float A = 0.f;
+            uint32_t f = inside ? GSX_RANK_NONE : k_cur;      // pixels outside the image do not vote
+            bool looked = false;                              // has the state AT k_cur been looked at
+            for (uint32_t start = begin; start < end; start += kBlock) {
+                const uint32_t i = start + threadIdx.x;
+                if (i < end) {
+                    const uint32_t r = ranks[i];
+                    s_rank[threadIdx.x] = r;
+                    const float4* R = rec + (size_t)3 * r;
+                    s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1];
+                }
+                __syncthreads();
+                const uint32_t cnt = min((uint32_t)kBlock, end - start);
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t r = s_rank[j];
+                    if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
+                    const float4 a = s_a[j], b = s_b[j];
+                    const float dx = gx - a.x, dy = gy - a.y;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float am = b.y * __builtin_amdgcn_exp2f(q);
+                    A = A + (1.0f - A) * am;
+                    if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
+                }
+                const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
+                if (all_found) break;
+            }
+            if (f == GSX_RANK_NONE && !looked && A > GSX_SAT_ALPHA) f = k_cur;     // the list ended at or before rank k_cur
+            mine = max(mine, f);
+        }
+        uint32_t v = mine;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
+            __hip_atomic_fetch_add(state + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = round * gridDim.x;
+            while (__hip_atomic_load(state + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+            s_k = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        const uint32_t cnt = min((uint32_t)kBlock, end - start);
-        for (uint32_t j = 0; j < cnt; j++) {
-            const float4 a = s_a[j], b = s_b[j];
-            const float dx = gx - a.x, dy = gy - a.y;
-            const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-            const float am = b.y * __builtin_amdgcn_exp2f(q);
-            A = A + (1.0f - A) * am;
-            if (sat == GSX_RANK_NONE && A > GSX_SAT_ALPHA) sat = s_rank[j];
-        }
-        if (__syncthreads_and(sat != GSX_RANK_NONE)) break;
+        const uint32_t k_new = s_k;
+        __syncthreads();                     // s_k and s_red are rewritten next round
+        result = k_new;
+        if (k_new == GSX_RANK_NONE || k_new == k_cur) break;      // never / a fixpoint (every workgroup reads the same value: uniform)
+        k_cur = k_new;
     }
-    uint32_t v = sat;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(state, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
-    __syncthreads();
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = result;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1109,7 +1144,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
-    saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
+    // (its grid barrier needs every workgroup resident: at most one per CU of the smallest part this runs on)
+    saturation_rank_kernel<<<dim3((unsigned)(n_tiles < kSatBlocks ? n_tiles : kSatBlocks)), dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);

@@ -263,6 +263,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
                           Mt[2]*dM[0] + Mt[3]*dM[2], Mt[2]*dM[1] + Mt[3]*dM[3] };
     float dC[4] = { -(t4[0]*Mt[0] + t4[1]*Mt[2]), -(t4[0]*Mt[1] + t4[1]*Mt[3]),
                     -(t4[2]*Mt[0] + t4[3]*Mt[2]), -(t4[2]*Mt[1] + t4[3]*Mt[3]) };
+    // a Gaussian behind the exit rank never reached the reference's loop (gaussian_splatting.py:118-148): its 2x2 inverse was
+    // never taken and no gradient flows through it -- not 0 * inf either, when its covariance is singular (world z ~ 0)
+    if (r >= limit) { dC[0] = 0.0f; dC[1] = 0.0f; dC[2] = 0.0f; dC[3] = 0.0f; }
     if (d_cov2d) {
         const float4 u = reinterpret_cast<const float4*>(d_cov2d)[g];
         dC[0] += u.x; dC[1] += u.y; dC[2] += u.z; dC[3] += u.w;

@@ -353,7 +353,8 @@ API void gsxo_preprocess_backward(const float* pos, const float* scl, const floa
                                   const uint32_t* order, int N,
                                   const double* d_rec, const float* d_mean2d, const float* d_depth,
                                   const float* d_cov2d,
-                                  double* g_pos, double* g_scl, double* g_rot, double* g_opa, double* g_fea)
+                                  double* g_pos, double* g_scl, double* g_rot, double* g_opa, double* g_fea,
+                                  int64_t n_composited /* ranks >= this were never composited (global exit); < 0: all were */)
 {
     (void)opacity; (void)features;
     #pragma omp parallel for schedule(static)
@@ -374,6 +375,9 @@ API void gsxo_preprocess_backward(const float* pos, const float* scl, const floa
                         Mt[2]*dM[0] + Mt[3]*dM[2], Mt[2]*dM[1] + Mt[3]*dM[3] };
         double dC[4] = { -(t[0]*Mt[0] + t[1]*Mt[2]), -(t[0]*Mt[1] + t[1]*Mt[3]),
                          -(t[2]*Mt[0] + t[3]*Mt[2]), -(t[2]*Mt[1] + t[3]*Mt[3]) };
+        /* a Gaussian behind the exit rank never reached the reference's loop (:118-148): its 2x2 inverse was never taken,
+         * and no gradient flows through it -- also not 0 * inf when its covariance is singular (world z ~ 0) */
+        if (n_composited >= 0 && r >= n_composited) dC[0] = dC[1] = dC[2] = dC[3] = 0.0;
         for (int i = 0; i < 4; i++) dC[i] += d_cov2d ? (double)d_cov2d[4*g+i] : 0.0;
         /* cov2d = J S3 J^T, J = [[j00,0,j02],[0,j11,j12]] */
         double J[6] = { o.J[0], 0, o.J[2], 0, o.J[1], o.J[3] };
@@ -466,9 +470,46 @@ API void gsxo_sort_ranges(const uint32_t* tile_of, const uint32_t* rank_of, int6
     free(cnt);
 }
 
+/* max over the pixels of f_p(k) = the first rank k' >= k after which pixel p's accumulated alpha is > 0.99 (between the
+ * instances of its tile a pixel keeps its value: "after rank k'" = after the tile's last instance of rank <= k');
+ * GSX_RANK_NONE if some pixel has no such rank. */
+static uint32_t next_all_saturated(const float* rec, int H, int W, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                                   uint32_t rank_limit, uint32_t k, const float* gx, const float* gy)
+{
+    int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
+    uint32_t kmax = 0; int never = 0;
+    #pragma omp parallel for schedule(dynamic, 1) reduction(max:kmax) reduction(||:never)
+    for (int t = 0; t < tw * th; t++) {
+        int tx = t % tw, ty = t / tw;
+        for (int y = ty*GSX_TILE; y < (ty+1)*GSX_TILE && y < H; y++)
+        for (int x = tx*GSX_TILE; x < (tx+1)*GSX_TILE && x < W; x++) {
+            float A = 0; uint32_t f = GSX_RANK_NONE;
+            uint32_t i = ranges[2*t];
+            for (; i < ranges[2*t+1]; i++) {                    /* the state at rank k: every instance of rank <= k */
+                uint32_t r = ranks_sorted[i];
+                if (r >= rank_limit || r > k) break;
+                A = A + (1.0f - A) * splat_alpha(rec + (size_t)GSX_REC_FLOATS * r, gx[x], gy[y]);
+            }
+            if (A > GSX_SAT_ALPHA) f = k;
+            for (; f == GSX_RANK_NONE && i < ranges[2*t+1]; i++) {
+                uint32_t r = ranks_sorted[i];
+                if (r >= rank_limit) break;
+                A = A + (1.0f - A) * splat_alpha(rec + (size_t)GSX_REC_FLOATS * r, gx[x], gy[y]);
+                if (A > GSX_SAT_ALPHA) f = r;
+            }
+            if (f == GSX_RANK_NONE) never = 1; else if (f > kmax) kmax = f;
+        }
+    }
+    return never ? GSX_RANK_NONE : kmax;
+}
+
 /* tiled forward: composite every tile's list up to rank_limit (exclusive; pass N for none).
- * Returns k* + 1 = number of ranks the reference would composite (N if some pixel never
- * saturates), computed as max over pixels of the first rank after which acc > 0.99. */
+ * Returns k* + 1 = number of ranks the reference would composite = the first k* after which EVERY pixel's accumulated
+ * alpha is > 0.99 at once (gaussian_splatting.py:147-148), N if there is none.  While alpha stays in [0, 1] the
+ * accumulated alpha only grows and k* is the max over pixels of the first rank after which acc > 0.99 (k0 below); an
+ * opacity outside [0, 1] can take a pixel back under the threshold, and then k* is the fixpoint of
+ * k <- max over pixels of the first rank >= k at which the pixel is saturated (non-decreasing, bounded by k*, and a
+ * fixpoint satisfies the reference's test).  Round 2 returned k0 here and disagreed with dense mode in that regime. */
 API int64_t gsxo_render_tiled(const float* rec, int N, int H, int W, const uint32_t* ranks_sorted,
                               const uint32_t* ranges, uint32_t rank_limit, float* rgb, float* acc, float* depth_map)
 {
@@ -498,6 +539,14 @@ API int64_t gsxo_render_tiled(const float* rec, int N, int H, int W, const uint3
             rgb[p] = C0; rgb[P+p] = C1; rgb[2*P+p] = C2; acc[p] = A;
             if (depth_map) depth_map[p] = Dm;
             if (sat == GSX_RANK_NONE) unsat = 1; else if (sat > kmax) kmax = sat;
+        }
+    }
+    if (!unsat) {
+        for (;;) {
+            uint32_t k2 = next_all_saturated(rec, H, W, ranks_sorted, ranges, rank_limit, kmax, gx, gy);
+            if (k2 == GSX_RANK_NONE) { unsat = 1; break; }
+            if (k2 == kmax) break;
+            kmax = k2;
         }
     }
     free(gx); free(gy);

