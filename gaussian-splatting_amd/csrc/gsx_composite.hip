@@ -87,8 +87,12 @@ __device__ __forceinline__ float edge_max(float kaa, float kab, float kbb, float
 }
 
 __device__ __forceinline__ uint32_t quad_mask(const float4& a, const float4& b, float box_x, float box_y, int qx, int qy,
-                                              const QuadEdges& E)
+                                              const QuadEdges& E, int cut_log2, int cut_min_exp, bool tiny)
 {
+    // an image less than a tile wide or high: every pair of the tile's list is evaluated, as the oracle's tiled mode does --
+    // its gradient tensors can consist of sub-cut weights altogether (a one-pixel column in every splat's far tail), and
+    // then ANY mask is a 100 % relative error (gsx_constants.h, GSX_CUT_LOG2_FOR)
+    if (tiny) return 0xFu;
     const uint32_t bx = __float_as_uint(box_x), by = __float_as_uint(box_y);
     const int xlo = (int)(bx & 0xffff) - qx, xhi = (int)(bx >> 16) - qx;
     const int ylo = (int)(by & 0xffff) - qy, yhi = (int)(by >> 16) - qy;
@@ -98,8 +102,8 @@ __device__ __forceinline__ uint32_t quad_mask(const float4& a, const float4& b, 
     const float k00 = a.z, kb = a.w, k11 = b.x;
     const bool proper = (k00 < 0.0f) && (k11 < 0.0f) && (4.0f * k00 * k11 - kb * kb > 0.0f);
     if (proper) {
-        const int e = max((int)((__float_as_uint(b.y) >> 23) & 0xff) - 127, GSX_CUT_MIN_EXP);           // |o| < 2^(e+1), floored like the box
-        const float thr = -(float)(GSX_CUT_LOG2 + 1 + e) - 0.0625f;               // margin for rounding
+        const int e = max((int)((__float_as_uint(b.y) >> 23) & 0xff) - 127, cut_min_exp);           // |o| < 2^(e+1), floored like the box
+        const float thr = -(float)(cut_log2 + 1 + e) - 0.0625f;               // margin for rounding
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float ulo = E.x[(k & 1) * 2] - a.x, uhi = E.x[(k & 1) * 2 + 1] - a.x;
@@ -200,6 +204,7 @@ __global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __res
 // chunk's proof needed the headers of everything in front of it.  A dozen trainer steps push a few hundred of six million
 // opacities below 0; that tripled the chunk pass of a config-5 view.)
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kMetaNonMono = 0x80u;               // meta word bit 7 (the low byte's codes are 1..5)
 constexpr uint32_t kHdrDone = 0x80000000u, kHdrUnbounded = 0x40000000u, kHdrGrowthMask = 0xFFFFFu;
 constexpr uint32_t kDeepChunks = 20480;                // a view is DEEP from this many chunks on (see chunk_order_kernel)
 constexpr int kDarkQ = 4 * GSX_CUT_LOG2;               // quarter-bits of darkness at which every weight is below the cut
@@ -517,6 +522,9 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     // o in [0, 2], <= 1 - o for o < 0 and <= o - 1 for o > 2; the sum of log2 of those factors over the chunk's splats
     // bounds log2(|T_k| / |T_start|) for every k.  Zero for ordinary opacities.
     float growth = 0.0f;
+    // can a splat of this chunk take a pixel's accumulated alpha DOWN (alpha outside [0, 1]: an opacity outside [0, 1], or an
+    // improper exponent)?  Bit 7 of the meta word; the combine pass needs it for the early-exit gate (kMetaNonMono)
+    bool nonmono = false;
     uint32_t cost = 0;                        // quadrant evaluations of this chunk (the backward's cost estimate)
     for (uint32_t bs = g.begin; bs < g.end && !stop; bs += kCBatch) {
         const uint32_t i = bs + lane;
@@ -526,9 +534,11 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             const uint32_t r = ranks[i];
             const float4* R = rec + (size_t)3 * r;
             const float4 a = R[0], b = R[1];
-            growth += growth_term(a, b);
+            const float gt = growth_term(a, b);
+            growth += gt;
+            nonmono = nonmono || (gt != 0.0f) || !(b.y <= 1.0f);      // (gt: o < 0, o > 2, improper, NaN; o in (1, 2] grows nothing but overshoots)
             const float4 c = R[2];
-            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE) & ~dark_quads;
+            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE) & ~dark_quads;
             if (PASS1) { past_exit = r >= limit; if (past_exit) my_mask = 0u; }      // ranks ascend: everything from the exit rank on is left out
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
@@ -580,12 +590,13 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         *state_ptr(chunk_state, chunk, 5, pix) = Dm[k];
     }
     growth = wave_sum(growth);
+    const bool any_nonmono = __builtin_amdgcn_ballot_w64(nonmono) != 0ull;
     // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
     const uint32_t gbits = (growth == 0.0f) ? 0u : (growth < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)growth + 2u : (uint32_t)GSX_META_GROWTH_MAX;
     // publish the payload (every lane its own word; zero = not there yet)
     if (publish) __hip_atomic_store(pay + (size_t)chunk * 64 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
-        chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT) | why;
+        chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (cost << GSX_META_COST_SHIFT) | why | (any_nonmono ? kMetaNonMono : 0u);
     }
     if (DEEP) {
         // every lane's word is on its way before the chunk's bit goes up; then, done: look for the tile's dark points on
@@ -640,6 +651,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const bool blocked = (tile_growth & kTileUnbounded) != 0u;
     const int dark_thr = kDarkQ + (int)(tile_growth & ~kTileUnbounded);
     bool for_good = false;                    // this wave's quadrant has passed its dark point (never without DEEP: `blocked`)
+    bool tile_nonmono = false;                // some splat of the tile's list can take A down (kMetaNonMono of its chunks)
     uint32_t skipped = 0;                     // bit u: this quadrant of chunk u of the (last) batch is dark -- the identity, computed or not
     for (uint32_t cb = c0; cb < c1; cb += kCombineBatch) {
         float l5[kCombineBatch];
@@ -650,7 +662,8 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         // of a config-5 view are 5 KB a chunk, and reading them all cost as much as the chunk pass)
         uint32_t meta_l = 0u;
         if (!for_good) {
-            if (need_bwd && (threadIdx.x & 63) < kCombineBatch) meta_l = chunk_meta[min(cb + (threadIdx.x & 63u), c1 - 1)];
+            if ((threadIdx.x & 63) < kCombineBatch) meta_l = chunk_meta[min(cb + (threadIdx.x & 63u), c1 - 1)];
+            tile_nonmono = tile_nonmono || __builtin_amdgcn_ballot_w64((meta_l & kMetaNonMono) != 0u) != 0ull;
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
                 const uint32_t c = min(cb + u, c1 - 1);
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                     // on e suffices): then |T| stays below 2^-24 throughout the chunk.  Pixels outside the image carry
                     // no gradient and count as dark
                     const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)meta_l, u) >> GSX_META_GROWTH_SHIFT;          // bits |T| may grow inside chunk c
-                    const bool darkp = gb < GSX_META_GROWTH_MAX && (!inside || m == 0.0f || e <= -GSX_CUT_LOG2 - (int)gb);
+                    const bool darkp = gb < GSX_META_GROWTH_MAX && !(H < GSX_TILE || W < GSX_TILE) && (!inside || m == 0.0f || e <= -GSX_CUT_LOG2_FOR(H, W) - (int)gb);
                     const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
                     if ((threadIdx.x & 63) == 0) {
                         reinterpret_cast<uint8_t*>(chunk_dark + c)[threadIdx.x >> 6] = all_dark ? 1 : 0;
@@ -744,7 +757,13 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         // splat with exp2(q) = inf (a Gaussian at the camera plane: its 2x2 covariance is not positive definite) somewhere in
         // the list, possibly BEHIND the rank at which the reference had already left its loop -- the exact search (F3) then
         // decides with the reference's own arithmetic, and finds no exit if such a pixel never saturated before the NaN
-        const bool unsat = inside && (A <= GSX_SAT_ALPHA - 1e-5f);
+        // Only a pixel whose list is MONOTONE vetoes: with every alpha in [0, 1] its A never was above its final value, so
+        // "not saturated at the end" means "never saturated" and the reference's test (every pixel > 0.99 at once) never
+        // held.  A pixel of a tile with a non-monotone splat may have been above 0.99 in the middle of its list and come
+        // back down (opacities in (1, 3]: tools/fuzz_parity.py seed 3480, exit after 2 of 7 with a final alpha of 0.84):
+        // it does not veto, and the exact search decides.  An empty tile is monotone: views that leave tiles empty -- every
+        // training view of the bench scene -- never reach the search, whatever their opacities do.
+        const bool unsat = inside && (A <= GSX_SAT_ALPHA - 1e-5f) && !tile_nonmono;
         // thousands of tiles raise the same flag: look before the atomic (4096 same-address atomics serialise in L2)
         if (__syncthreads_or(unsat) && threadIdx.x == 0 &&
             __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(state + 1, 1u);
@@ -1019,7 +1038,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
             const float4 a = R[0], b = R[1];
-            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE) & ~dark_mask;
+            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE) & ~dark_mask;
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
         }
         // The batch's quadrant masks as four wave-uniform bit sets (bit j of qk: instance j reaches quadrant k, dark quadrants

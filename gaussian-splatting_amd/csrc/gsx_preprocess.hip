@@ -145,8 +145,8 @@ __device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ 
     const float op = p1.w;
     // footprint box (bit-exact contract with oracle footprint())
     uint32_t ob = __float_as_uint(op) & 0x7fffffffu;
-    const int e = max((int)(ob >> 23) - 127, GSX_CUT_MIN_EXP);
-    const int mm = e + 1 + GSX_CUT_LOG2;
+    const int e = max((int)(ob >> 23) - 127, GSX_CUT_MIN_EXP_FOR(H, W));
+    const int mm = e + 1 + GSX_CUT_LOG2_FOR(H, W);
     int xlo = 1, ylo = 1, xhi = 0, yhi = 0;
     if (!(ob < 0x7f800000u && mm <= 0)) {
         bool full = !(ob < 0x7f800000u);

@@ -177,8 +177,8 @@ static void footprint(float mx, float my, float a, float d, float det, float op,
 {
     uint32_t ob; memcpy(&ob, &op, 4); ob &= 0x7fffffffu;
     int e = (int)(ob >> 23) - 127;                 /* |o| < 2^(e+1) */
-    if (e < GSX_CUT_MIN_EXP) e = GSX_CUT_MIN_EXP;  /* sized as if |o| were at least 2^-6: keeps d alpha / d opacity (gsx_constants.h) */
-    int m = e + 1 + GSX_CUT_LOG2;
+    if (e < GSX_CUT_MIN_EXP_FOR(H, W)) e = GSX_CUT_MIN_EXP_FOR(H, W);  /* sized as if |o| were at least the floor: keeps d alpha / d opacity (gsx_constants.h) */
+    int m = e + 1 + GSX_CUT_LOG2_FOR(H, W);
     rc[0] = rc[1] = rc[2] = rc[3] = 0;
     px[0] = px[1] = 1; px[2] = px[3] = 0;          /* empty box: lo > hi */
     if (ob < 0x7f800000u && m <= 0) return;                              /* |alpha| < 2^-CUT everywhere */

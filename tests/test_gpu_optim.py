@@ -189,13 +189,17 @@ def test_trainer_three_steps_match_reference(fused):
     """three trainer steps (zero_grad, forward, loss, backward, clip_grad_norm_(0.1), Adam with the
     reference's five learning rates) on the reference itself (tests/golden/train3_400_32x24.npz, made by
     make_golden.py::run_train_case) against the same steps through this path (fused HIP clip+Adam and loss, or torch's).
-    Bars: losses 1e-5 relative; first step's clipped gradients 1e-3 of the tensor's max; parameters after each step:
-    EVERY element whose reference gradient is well above Adam's eps within 2 % of lr per step; 99 % of all elements within
-    5 % of ONE step's travel (lr).  Adam turns a gradient g into a step lr g / (|g| + 1e-8): an element whose reference
-    gradient is of the order of eps (contributions of pairs beyond the footprint cut, where exp(-q/2) < 2^-18: ~1e-9 after
-    the 1/(3HW) of the loss) moves by a fraction of lr in the reference where this path, with an exactly zero gradient,
-    leaves it still -- ill-conditioned in the reference too, bounded by lr per step.  Measured q99 for the scales (the
-    worst tensor) after step 2: 0.2 % of lr with the cut at 2^-24, 3.2 % at 2^-20 (the current cut), 6.6 % after step 1 at 2^-18."""
+    Bars: losses 1e-5 relative; first step's clipped gradients 1e-3 of the tensor's max; parameters after step s:
+    EVERY element whose reference gradient is well above Adam's eps within 2 % of lr per step, and 99 % of ALL elements
+    within 2 % of lr PER STEP (s x 2 %: the differences add up from step to step).  Adam turns a gradient g into a step
+    lr g / (|g| + 1e-8): an element whose reference gradient is of the order of eps (contributions of pairs beyond the
+    footprint cut, where exp(-q/2) < 2^-18: ~1e-9 after the 1/(3HW) of the loss) moves by a fraction of lr in the reference
+    where this path, with an exactly zero gradient, leaves it still -- ill-conditioned in the reference too, bounded by lr
+    per step.  Measured on this tree (tools/trainer_fixture_q99.py -> profiles/r3_trainer_fixture_q99.json, cut 2^-20),
+    q99 over all elements in units of lr after steps 1 / 2 / 3: scales (the worst tensor) 1.1 / 3.2 / 4.6 %, positions
+    0.1 / 0.7 / 1.0 %, rotations 0.06 / 0.3 / 0.5 %, opacity and colour < 0.02 %; the well-conditioned elements (84-94 % of a
+    tensor; 63 % of the rotations) stay within 0.06 % of lr.  (Round 1's 2^-24 cut: scales 0.2 % after step 2; a 2^-18 cut:
+    6.6 % after step 1 -- which is why the cut stopped at 2^-20.)"""
     import os
     from gaussian_splatting_amd import GaussianSplat
     from gaussian_splatting_amd.trainer import make_optimizer, train_step, reference_regularised_mse, DEFAULT_LRS
@@ -218,7 +222,7 @@ def test_trainer_three_steps_match_reference(fused):
         for k in names:
             d = np.abs(getattr(m, k).detach().cpu().numpy() - fx[f"after{s + 1}_{k}"]).ravel()
             lr = DEFAULT_LRS[k]
-            assert np.quantile(d, 0.99) <= 0.05 * lr, (s, k, float(np.quantile(d, 0.99)), lr)
+            assert np.quantile(d, 0.99) <= 0.02 * lr * (s + 1), (s, k, float(np.quantile(d, 0.99)), lr)
             assert d.max() <= (s + 1) * lr * 1.01, (s, k, float(d.max()))
             # the bound above is vacuous for Adam (nothing moves further than lr per step), so: EVERY element whose
             # reference gradient is well above Adam's eps (1e-8) -- where the update -lr g / (|g| + eps) is a well-conditioned

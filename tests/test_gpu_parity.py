@@ -872,7 +872,7 @@ def test_random_scenes_vs_oracle(dev, O):
             R.backward_view(t["P"], vs, torch.from_numpy(d_rgb).to(dev), None, None, None, grads_f, accumulate=False)
             torch.cuda.synchronize()
             go = O.backward(params, pose, H, W, fw, d_rgb, None, None, None, "tiled")
-            floor = 2.0 ** -18 * H * W          # what the footprint cut may drop (exp(-q/2) < 2^-18 per pair, upstream of order 1)
+            floor = 1e-30                       # no floor under the yardstick: the tensor's own maximum
             for k, gf in zip(PARAMS, grads_f):
                 assert np.array_equal(gf.cpu().numpy(), gr[k], equal_nan=True), (seed, k)
                 if np.all(np.isfinite(go[k])):

@@ -60,10 +60,9 @@ for seed in range(first, first + cases):
         for k, gf in zip(PARAMS, grads_f):
             assert np.array_equal(gf.cpu().numpy(), gr[k], equal_nan=True), f"fused backward differs: {k}"
         go = O.backward(params, pose, H, W, fw, d_rgb, d_m, d_d, d_c, "tiled")
-        # a gradient tensor that is zero up to what the footprint cut may drop has no meaningful relative error: every dropped
-        # pair has exp(-q/2) < 2^-18 (gsx_constants.h), times an upstream gradient of order 1, summed over the pixels --
-        # floor the yardstick there (matters for 1-pixel-wide images whose only row lies in every splat's far tail)
-        floor = 2.0 ** -18 * H * W
+        # no floor under the yardstick (round 2 floored it at 2^-18 H W, which hid 13 flags in 1500 on one-pixel-wide images:
+        # images less than a tile wide or high now keep the 2^-24 cut, gsx_constants.h)
+        floor = 1e-30
         for k in PARAMS:
             if np.all(np.isfinite(go[k])):
                 err = float(np.abs(gr[k].astype(np.float64) - go[k]).max()) / max(float(np.abs(go[k]).max()), floor)

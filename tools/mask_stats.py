@@ -40,7 +40,7 @@ for v in views:
     xlo, xhi = (bx & 0xffff) - qx, ((bx >> 16) & 0xffff) - qx
     ylo, yhi = (by & 0xffff) - qy, ((by >> 16) & 0xffff) - qy
     proper = (k00 < 0) & (k11 < 0) & (4 * k00 * k11 - kb * kb > 0)
-    e = (((o.view(torch.int32) >> 23) & 0xff) - 127).clamp(min=-7)      # GSX_CUT_MIN_EXP
+    e = (((o.view(torch.int32) >> 23) & 0xff) - 127).clamp(min=-3)      # GSX_CUT_MIN_EXP
     thr = -(24 + 1 + e).float() - 0.0625
     cnt = torch.zeros(D, dtype=torch.long, device=dev)
     cnt_box = torch.zeros(D, dtype=torch.long, device=dev)
