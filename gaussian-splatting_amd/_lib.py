@@ -13,7 +13,7 @@ SYMBOLS = [
     "gsx_strerror", "gsx_last_hip_error", "gsx_abi_version",
     "gsx_project_fwd", "gsx_sort_workspace_bytes", "gsx_sort_pairs_u32", "gsx_sort_pairs_u32_static",
     "gsx_scan_workspace_bytes", "gsx_scan_u32", "gsx_build_records",
-    "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks",
+    "gsx_bin_workspace_bytes", "gsx_bin_instances", "gsx_bin_count", "gsx_bin_emit_sort", "gsx_max_chunks", "gsx_chunk_state_floats",
     "gsx_view_layout", "gsx_view_forward",
     "gsx_composite_fwd", "gsx_composite_bwd", "gsx_preprocess_bwd",
     "gsx_clip_adam_workspace_bytes", "gsx_clip_adam_step",
@@ -24,7 +24,7 @@ SYMBOLS = [
     "gsx_comm_available", "gsx_comm_unique_id", "gsx_comm_init", "gsx_allreduce_avg", "gsx_bcast", "gsx_comm_destroy",
 ]
 
-ABI_VERSION = 19            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
+ABI_VERSION = 20            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE, GSX_E_AGAIN, GSX_E_COMM = 0, -1, -2, -3, -4, -5, -6
 RANK_NONE = 0xFFFFFFFF
 REC_FLOATS = 12
@@ -91,6 +91,7 @@ def lib():
     L.gsx_bin_count.argtypes = [_p, _p, _i32, _p, _p, _p, _p, _sz, _p]
     L.gsx_bin_emit_sort.argtypes = [_p, _p, _p, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]
     L.gsx_max_chunks.restype = _i64; L.gsx_max_chunks.argtypes = [_i64, _i32, _i32, _i32]
+    L.gsx_chunk_state_floats.restype = _i64; L.gsx_chunk_state_floats.argtypes = [_i64]
     L.gsx_view_layout.restype = _i64; L.gsx_view_layout.argtypes = [_i32, _i32, _i32, _i64, _i32, _i32, _p, _p]
     L.gsx_view_forward.argtypes = [_p] * 6 + [_i32, _i32, _i32, _i64, _i32, _p, _i32, _i32, _p, _i64] + [_p] * 7 + [_p, _p, _p]
     L.gsx_composite_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p]
@@ -123,7 +124,7 @@ def lib():
     L.gsx_l1_ssim_bwd.argtypes = [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _sz, _p, _p]
     for name in SYMBOLS:
         getattr(L, name)
-        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name not in ("gsx_max_chunks", "gsx_view_layout"):
+        if name not in ("gsx_strerror", "gsx_last_hip_error", "gsx_abi_version") and not name.endswith("_bytes") and name not in ("gsx_max_chunks", "gsx_view_layout", "gsx_chunk_state_floats"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

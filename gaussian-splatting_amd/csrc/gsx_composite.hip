@@ -30,10 +30,13 @@ constexpr int kCBatch = 64;            // records staged per LDS batch (one per 
 // and dark words: 16 counters (two sets of 8: normal pass / pass after a global early exit), then for each set
 // kWorkClasses lists of max_chunks chunk ids.
 constexpr int kWorkClasses = 5;
+// a list entry: chunk id | kItemFront (the first half of a chunk cut in two) | kItemBack (its second half); a chunk in two
+// halves is two entries, so a list has room for 2 x max_chunks of them
+constexpr uint32_t kItemFront = 0x80000000u, kItemBack = 0x40000000u, kItemChunk = 0x3FFFFFFFu;
 __device__ __forceinline__ uint32_t* work_counters(uint32_t* work, bool pass1) { return work + (pass1 ? 8 : 0); }
 __device__ __forceinline__ uint32_t* work_list(uint32_t* work, bool pass1, int cls, uint32_t max_chunks)
 {
-    return work + 16 + ((size_t)(pass1 ? kWorkClasses : 0) + (size_t)cls) * max_chunks;
+    return work + 16 + ((size_t)(pass1 ? kWorkClasses : 0) + (size_t)cls) * 2u * max_chunks;
 }
 constexpr int kPixPerTile = GSX_TILE * GSX_TILE;
 
@@ -206,12 +209,18 @@ __global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __res
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMetaNonMono = 0x80u;               // meta word bit 7 (the low byte's codes are 1..5)
 constexpr uint32_t kHdrDone = 0x80000000u, kHdrUnbounded = 0x40000000u, kHdrGrowthMask = 0xFFFFFu;
-constexpr uint32_t kDeepChunks = 20480;                // a view is DEEP from this many chunks on (see chunk_order_kernel)
+constexpr uint32_t kDeepChunks = GSX_DEEP_CHUNKS;      // a view is DEEP from this many chunks on (see chunk_order_kernel)
 constexpr int kDarkQ = 4 * GSX_CUT_LOG2;               // quarter-bits of darkness at which every weight is below the cut
 constexpr int kPayBias = 65;                           // payload byte = q + 65 in [1, 255] (0 = not published): q in [-64, 190]
 // tail of the chunk-state buffer behind the states, in words per chunk: meta 1, dark 1, work lists 2 x kWorkClasses (+ 16
 // counters), header 1, order table 1, payload 64
-__device__ __host__ __forceinline__ size_t tail_hdr_offset(size_t max_chunks) { return 2 * max_chunks + 16 + 2 * (size_t)kWorkClasses * max_chunks; }
+__device__ __host__ __forceinline__ size_t tail_hdr_offset(size_t max_chunks) { return 2 * max_chunks + 16 + 2 * (size_t)kWorkClasses * 2 * max_chunks; }
+// mid-chunk states of a shallow view: behind header, order table and payloads (gsx_constants.h)
+__device__ __host__ __forceinline__ size_t tail_mid_offset(size_t max_chunks) { return tail_hdr_offset(max_chunks) + 66 * max_chunks; }
+__device__ __forceinline__ float* mid_ptr(float* mid_state, uint32_t chunk, int word, int pix)
+{
+    return mid_state + ((size_t)chunk * GSX_MID_WORDS + word) * kPixPerTile + pix;
+}
 
 // one splat's contribution to its chunk's growth bound (bits): log2 |1 - o| for an opacity outside [0, 2] (+ slack for the
 // rounding of the sum); NaN stays NaN
@@ -613,6 +622,155 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// F1w (round 3): the chunk pass of a SHALLOW view -- one WORKGROUP of four waves per chunk.  Wave w composites the chunk's
+// w-th quarter (at most 64 instances: one staged batch, no batch loop) from (C = 0, T = 1); the four partial results are
+// merged IN ORDER through LDS (compositing is associative), wave w merging the tile's quadrant w, and one state per chunk
+// is written as before -- so the chunk stays the unit of state and of the combine pass, while the unit of LATENCY is a
+// quarter of it.  Why: with one wave per chunk the kernel took about as long as two of its longest work items (a full
+// 256-instance chunk is ~17 k wave-instructions: ~80 us on a SIMD it shares with four others), the machine spent the
+// second half of the launch draining (3.3 of 5 wave slots resident on average, SQ counters of round 2), and the VALU ran
+// at the two-waves-per-SIMD rate (profiles/r3_valu_issue_rate.txt).  Four waves of a workgroup sit on the four SIMDs of
+// one CU: every SIMD gets an equal share of every chunk.
+// The merge also leaves the local result of the chunk's SECOND HALF (quarters 2 and 3) in mid_state: the backward starts
+// the first half from it on a wave of its own (chunk_bwd_kernel).
+// Not bit-identical to the one-wave kernel (the products are associated differently); deterministic like it.
+// ------------------------------------------------------------------------------------------
+template <bool DEPTH>
+__global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
+    const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
+    const uint32_t* __restrict__ chunk_base, int n_tiles, int H, int W, int tw, float stepx, float stepy,
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
+    float* __restrict__ mid_state)
+{
+    constexpr int kWords = 6;                 // C0 C1 C2 m e Dm
+    // [wave][word][pixel of the tile]; the head of a wave's part doubles as its record staging (3 x 64 float4 = 3 KB of 6 KB),
+    // which is dead when the wave parks its result there
+    __shared__ float s_part[4][kWords][kPixPerTile];
+    __shared__ uint32_t s_cost[4], s_nonmono[4];
+    __shared__ float s_growth[4];
+    if (blockIdx.x == 0) {                    // the combine pass (next launch) counts in these; the chunk pass itself reads neither
+        if (threadIdx.x < 4) state[threadIdx.x] = 0u;
+        if (threadIdx.x < 16) work[threadIdx.x] = 0u;
+    }
+    const uint32_t n_chunks = chunk_base[n_tiles];
+    if (n_chunks >= kDeepChunks || blockIdx.x >= n_chunks) return;      // a deep view is the other kernel's (uniform over the workgroup)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
+    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    const uint32_t sub = chunk_base[n_tiles + 1] >> 2;                  // 64, 32 or 16 instances per wave
+    const uint32_t my_begin = min(g.begin + (uint32_t)wave * sub, g.end), my_end = min(my_begin + sub, g.end);
+    float4* s_a = reinterpret_cast<float4*>(&s_part[wave][0][0]);
+    float4* s_b = s_a + kCBatch;
+    float4* s_c = s_b + kCBatch;
+    const int x0 = g.tx * GSX_TILE + (lane & 7), y0 = g.ty * GSX_TILE + (lane >> 3);
+    float gx[2], gy[2];
+    gx[0] = pix_coord(min(x0, W - 1), W, stepx); gx[1] = pix_coord(min(x0 + 8, W - 1), W, stepx);
+    gy[0] = pix_coord(min(y0, H - 1), H, stepy); gy[1] = pix_coord(min(y0 + 8, H - 1), H, stepy);
+    const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
+    float C0[4], C1[4], C2[4], Dm[4], m[4]; int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { C0[k] = C1[k] = C2[k] = Dm[k] = 0.f; m[k] = 1.f; e[k] = 0; }
+    float growth = 0.0f;
+    bool nonmono = false;
+    uint32_t cost = 0;
+    if (my_begin < my_end) {                  // (wave-uniform)
+        const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
+        const uint32_t i = my_begin + lane;
+        uint32_t my_mask = 0u;
+        if (i < my_end) {
+            const uint32_t r = ranks[i];
+            const float4* R = rec + (size_t)3 * r;
+            const float4 a = R[0], b = R[1];
+            const float gt = growth_term(a, b);
+            growth = gt;
+            nonmono = (gt != 0.0f) || !(b.y <= 1.0f);
+            const float4 c = R[2];
+            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE);
+            s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
+        }
+        const unsigned long long q0 = __builtin_amdgcn_ballot_w64((my_mask & 1u) != 0u), q1 = __builtin_amdgcn_ballot_w64((my_mask & 2u) != 0u);
+        const unsigned long long q2 = __builtin_amdgcn_ballot_w64((my_mask & 4u) != 0u), q3 = __builtin_amdgcn_ballot_w64((my_mask & 8u) != 0u);
+        // the staging area is this wave's own: its LDS instructions execute in order, no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t active = 0;
+        for (unsigned long long todo = (q0 | q1) | (q2 | q3); todo != 0ull; ) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);           // front to back
+            todo &= todo - 1ull;
+            const float4 a = s_a[j], b = s_b[j], c = s_c[j];
+            const unsigned long long bit = 1ull << j;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
+                    const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float al = b.y * __builtin_amdgcn_exp2f(q);
+                    const float w = ldexpf(m[k], e[k]) * al;
+                    C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
+                    if (DEPTH) Dm[k] += w * c.y;
+                    m[k] *= one_minus(al);
+                }
+            }
+            if ((++active & 3u) == 0u) {                       // every 4 composited splats: |m| stays within 2^+-120
+#pragma unroll
+                for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
+            }
+        }
+        cost = (uint32_t)(__popcll(q0) + __popcll(q1)) + (uint32_t)(__popcll(q2) + __popcll(q3));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();       // every lane has read its last record before the result goes over the staging area
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        renorm(m[k], e[k]);
+        const int pix = k * 64 + lane;
+        s_part[wave][0][pix] = C0[k]; s_part[wave][1][pix] = C1[k]; s_part[wave][2][pix] = C2[k];
+        s_part[wave][3][pix] = m[k]; s_part[wave][4][pix] = __int_as_float(e[k]);
+        if (DEPTH) s_part[wave][5][pix] = Dm[k];
+    }
+    growth = wave_sum(growth);
+    const bool any_nonmono = __builtin_amdgcn_ballot_w64(nonmono) != 0ull;
+    if (lane == 0) { s_cost[wave] = cost; s_growth[wave] = growth; s_nonmono[wave] = any_nonmono ? 1u : 0u; }
+    __syncthreads();
+    // merge: wave w takes quadrant w (pixel = threadIdx.x), the four quarters in list order
+    {
+        const int pix = threadIdx.x;
+        float A0 = 0.f, A1 = 0.f, A2 = 0.f, AD = 0.f, am = 1.f; int ae = 0;        // the whole chunk
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, bm = 1.f; int be = 0;                  // its second half (quarters 2, 3)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float c0 = s_part[j][0][pix], c1 = s_part[j][1][pix], c2 = s_part[j][2][pix];
+            const float mj = s_part[j][3][pix]; const int ej = __float_as_int(s_part[j][4][pix]);
+            const float Tv = ldexpf(am, ae);
+            A0 += Tv * c0; A1 += Tv * c1; A2 += Tv * c2;
+            if (DEPTH) AD += Tv * s_part[j][5][pix];
+            am *= mj; ae += ej; renorm(am, ae);
+            if (j >= 2) {
+                const float Tb = ldexpf(bm, be);
+                B0 += Tb * c0; B1 += Tb * c1; B2 += Tb * c2;
+                bm *= mj; be += ej; renorm(bm, be);
+            }
+        }
+        *state_ptr(chunk_state, chunk, 0, pix) = A0; *state_ptr(chunk_state, chunk, 1, pix) = A1; *state_ptr(chunk_state, chunk, 2, pix) = A2;
+        *state_ptr(chunk_state, chunk, 3, pix) = am; *state_ptr(chunk_state, chunk, 4, pix) = __int_as_float(ae);
+        *state_ptr(chunk_state, chunk, 5, pix) = AD;
+        if (mid_state) {
+            *mid_ptr(mid_state, chunk, 0, pix) = B0; *mid_ptr(mid_state, chunk, 1, pix) = B1; *mid_ptr(mid_state, chunk, 2, pix) = B2;
+            *mid_ptr(mid_state, chunk, 3, pix) = bm; *mid_ptr(mid_state, chunk, 4, pix) = __int_as_float(be);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const float gsum = (s_growth[0] + s_growth[1]) + (s_growth[2] + s_growth[3]);
+        const uint32_t csum = (s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3]);
+        const uint32_t nm = (s_nonmono[0] | s_nonmono[1]) | (s_nonmono[2] | s_nonmono[3]);
+        // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
+        const uint32_t gbits = (gsum == 0.0f) ? 0u : (gsum < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)gsum + 2u : (uint32_t)GSX_META_GROWTH_MAX;
+        chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (csum << GSX_META_COST_SHIFT) | (nm ? kMetaNonMono : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // F2: one workgroup per tile, thread = pixel.  Forward scan over the tile's chunks (prefix
 // transmittance, image), then -- for training -- a backward scan that replaces each chunk's
 // local colour by the colour BEHIND it (per unit transmittance at the chunk's end).
@@ -626,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
     uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pay,
     uint32_t max_chunks, int n_tiles,
-    float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
+    float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map, const uint32_t* __restrict__ ranges, int split_halves)
 {
     if (PASS1) { if (rank_limit_from_state(state, N) >= N) return; }
     if (!PASS1 && DEEP != (chunk_base[n_tiles] >= kDeepChunks)) return;              // the other instantiation's view
@@ -719,14 +877,25 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
                 const uint32_t c = cb + threadIdx.x;
                 const bool valid = threadIdx.x < kCombineBatch && c < c1;
                 int cls = -1;
+                bool halves = false;          // this chunk goes into the list as two entries (first half, second half)
                 if (valid) {
                     const uint32_t meta = chunk_meta[c];
                     const uint32_t n_dark = (uint32_t)(s_dark[threadIdx.x][0] + s_dark[threadIdx.x][1] + s_dark[threadIdx.x][2] + s_dark[threadIdx.x][3]);
-                    const uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * chunk size
+                    uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);      // <= 4 * 4 * chunk size
                     const uint32_t ch = chunk_base[n_tiles + 1];
+                    // A shallow view's chunks of 128 or 256 instances with something in both halves: the chunk pass left the
+                    // second half's local result (mid_state), so the first half can start on a wave of its own.  Not the
+                    // occluded ones (nothing to compute), not after a global early exit (pass 1 rewrites the states only).
+                    if (!PASS1 && split_halves && ch >= 128u && n_dark != 4u) {
+                        const uint32_t len = (c + 1u < c1) ? ch : (ranges[2 * tile + 1] - ranges[2 * tile]) - (c - c0) * ch;
+                        halves = len > (ch >> 1);
+                    }
+                    if (halves) est >>= 1;
                     cls = n_dark == 4u ? 4 : est >= 10u * ch ? 0 : est >= 6u * ch ? 1 : est >= 3u * ch ? 2 : 3;
+                    if (halves) cls = est >= 5u * ch ? 0 : est >= 3u * ch ? 1 : est >= 3u * (ch >> 1) ? 2 : 3;
                 }
                 const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+                const unsigned long long hv = __builtin_amdgcn_ballot_w64(halves);
                 uint32_t* cnt = work_counters(work, PASS1);
                 // lane k reserves class k's slots: the five atomics are in flight together (one L2 round trip per batch;
                 // issued one after the other they were most of a long tile's time in this kernel)
@@ -734,13 +903,17 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 #pragma unroll
                 for (int k = 0; k < kWorkClasses; k++) {
                     const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == k);
-                    if ((int)threadIdx.x == k) mine = (uint32_t)__popcll(mk);
-                    if (cls == k) below = (uint32_t)__popcll(mk & lt);
+                    if ((int)threadIdx.x == k) mine = (uint32_t)(__popcll(mk) + __popcll(mk & hv));
+                    if (cls == k) below = (uint32_t)(__popcll(mk & lt) + __popcll(mk & hv & lt));
                 }
                 uint32_t base = 0;
                 if (threadIdx.x < kWorkClasses && mine) base = atomicAdd(cnt + threadIdx.x, mine);
                 base = (uint32_t)__shfl((int)base, cls < 0 ? 0 : cls, 64);
-                if (cls >= 0) work_list(work, PASS1, cls, max_chunks)[base + below] = c;
+                if (cls >= 0) {
+                    uint32_t* list = work_list(work, PASS1, cls, max_chunks);
+                    if (halves) { list[base + below] = c | kItemBack; list[base + below + 1u] = c | kItemFront; }
+                    else list[base + below] = c;
+                }
             }
             __syncthreads();
         }
@@ -952,7 +1125,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
-    const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed)
+    const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed,
+    uint32_t max_chunks, const float* __restrict__ mid_state)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
@@ -968,8 +1142,15 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     int cls = 0;
     while (cls < kWorkClasses && b >= cnt[cls]) { b -= cnt[cls]; cls++; }       // costliest class first
     if (cls == kWorkClasses) return;
-    const uint32_t chunk = work_list(const_cast<uint32_t*>(work), after_exit, cls, gridDim.x)[b];
-    const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    const uint32_t item = work_list(const_cast<uint32_t*>(work), after_exit, cls, max_chunks)[b];
+    const uint32_t chunk = item & kItemChunk;
+    ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    // a chunk in two halves (shallow views: the combine pass made two entries of it): this wave walks one of them
+    const bool front = (item & kItemFront) != 0u;
+    if (item & (kItemFront | kItemBack)) {
+        const uint32_t mid = g.begin + (chunk_base[n_tiles + 1] >> 1);
+        if (front) g.end = mid; else g.begin = mid;
+    }
     // instances of this chunk that were composited: ranks ascend, keep those below the exit rank
     uint32_t eff_end = g.end;
     if (limit < N) {
@@ -1020,8 +1201,19 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         if (x < W && y < H) { const size_t p = (size_t)y * W + x; G0[k] = d_rgb[p]; G1[k] = d_rgb[P + p]; G2[k] = d_rgb[2*P + p]; }
         const int pix = k * 64 + lane;
         const float* cs = chunk_state + (size_t)chunk * GSX_STATE_WORDS * kPixPerTile + pix;
-        Wb[k] = G0[k] * cs[0 * kPixPerTile] + G1[k] * cs[1 * kPixPerTile] + G2[k] * cs[2 * kPixPerTile];
-        m[k] = cs[6 * kPixPerTile]; e[k] = __float_as_int(cs[7 * kPixPerTile]);
+        float b0 = cs[0 * kPixPerTile], b1 = cs[1 * kPixPerTile], b2 = cs[2 * kPixPerTile];      // colour behind the chunk
+        m[k] = cs[6 * kPixPerTile]; e[k] = __float_as_int(cs[7 * kPixPerTile]);                  // transmittance at its end
+        if (front) {
+            // the state at the chunk's MIDDLE from the second half's local result (C_b, T_b) the chunk pass left: the colour
+            // behind the middle is C_b + T_b * (colour behind the chunk), the transmittance there T_end / T_b -- the quotient
+            // the second half's wave reaches by dividing its (1 - alpha)s out one by one
+            const float* ms = mid_state + (size_t)chunk * GSX_MID_WORDS * kPixPerTile + pix;
+            const float tb = ldexpf(ms[3 * kPixPerTile], __float_as_int(ms[4 * kPixPerTile]));
+            b0 = ms[0 * kPixPerTile] + tb * b0; b1 = ms[1 * kPixPerTile] + tb * b1; b2 = ms[2 * kPixPerTile] + tb * b2;
+            m[k] *= __builtin_amdgcn_rcpf(ms[3 * kPixPerTile]); e[k] -= __float_as_int(ms[4 * kPixPerTile]);
+            renorm(m[k], e[k]);
+        }
+        Wb[k] = G0[k] * b0 + G1[k] * b1 + G2[k] * b2;
     }
     const uint32_t nb = (eff_end - g.begin + kCBatch - 1) / kCBatch;
     uint32_t active = 0;
@@ -1116,18 +1308,19 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     if (!ranges || !chunk_base || !state || !rgb || !alpha) return GSX_E_INVALID;
     // an empty model (N == 0) has no records: every tile's list is empty, the chunk table says 0 chunks, nothing reads `rec`
     if (max_chunks > 0 && ((N > 0 && !rec) || !ranks_sorted || !chunk_state)) return GSX_E_INVALID;
-    if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
+    if (max_chunks > (int64_t)kItemChunk) return GSX_E_RANGE;            // (the work lists' entries keep two bits for the halves)
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     const float sx = lin_step(W), sy = lin_step(H);
     const float4* r4 = (const float4*)rec;
     uint32_t* meta = reinterpret_cast<uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
-    uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of max_chunks
+    uint32_t* work = meta + 2 * (size_t)max_chunks;          // 16 counters, 2 x kWorkClasses lists of 2 x max_chunks entries
+    float* mid_state = reinterpret_cast<float*>(meta + tail_mid_offset((size_t)max_chunks));      // shallow views: second-half results per chunk
     const bool could_be_deep = (uint64_t)max_chunks >= kDeepChunks;
     // first dark level per (tile, quadrant) of a deep view (entry_walk): in the work lists' room, which the combine pass only
     // fills after the chunk pass (none if the image has more tiles than that holds: then nothing is skipped)
-    uint32_t* tile_dark = (could_be_deep && 4 * (size_t)n_tiles <= 2 * (size_t)kWorkClasses * (size_t)max_chunks) ? work + 16 : nullptr;
+    uint32_t* tile_dark = (could_be_deep && 4 * (size_t)n_tiles <= 4 * (size_t)kWorkClasses * (size_t)max_chunks) ? work + 16 : nullptr;
     // the shallow instantiation only has work below kDeepChunks chunks: its grid need not be larger
     const dim3 gc((unsigned)max_chunks), gc0((unsigned)(could_be_deep ? kDeepChunks - 1 : max_chunks)), gt((unsigned)n_tiles);
     uint32_t* hdr = meta + tail_hdr_offset((size_t)max_chunks);                             // published headers, level-order table, payloads
@@ -1151,15 +1344,15 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_kernel<false, true, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
+        if (max_chunks > 0) chunk_fwd_wg_kernel<true><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
-        if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        tile_combine_kernel<false, true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
+        if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
-        if (max_chunks > 0) chunk_fwd_kernel<false, false, false><<<gc0, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
+        if (max_chunks > 0) chunk_fwd_wg_kernel<false><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
-        if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+        tile_combine_kernel<false, false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
+        if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
@@ -1168,10 +1361,10 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
-            tile_combine_kernel<true, true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            tile_combine_kernel<true, true, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
         } else {
             chunk_fwd_kernel<true, false, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
-            tile_combine_kernel<true, false, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map);
+            tile_combine_kernel<true, false, true><<<gt1, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
         }
     }
     GSX_LAUNCH_CHECK();
@@ -1186,7 +1379,7 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
     if (N == 0 || max_chunks == 0) return GSX_OK;
     if (!rec || !ranks_sorted || !ranges || !chunk_base || !offsets || !chunk_state || !state || !d_rgb || !partials) return GSX_E_INVALID;
-    if (max_chunks > 0x7fffffffll) return GSX_E_RANGE;
+    if (max_chunks > (int64_t)kItemChunk) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     if (n_rows < 0) return GSX_E_INVALID;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE;
@@ -1196,15 +1389,21 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     // view has few such chunks and the fill would only cost.
     const int prezeroed = n_rows >= GSX_PREZERO_ROWS ? 1 : 0;
     if (prezeroed) GSX_HIP(hipMemsetAsync(partials, 0, (size_t)n_rows * 9 * sizeof(float), (hipStream_t)stream));
-    chunk_bwd_kernel<<<dim3((unsigned)max_chunks), dim3(64), 0, (hipStream_t)stream>>>(
+    const uint32_t* meta = reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
+    // one workgroup per work item: a chunk, or -- in a shallow view -- half a chunk (at most kDeepChunks - 1 chunks are cut)
+    const int64_t grid = max_chunks + (max_chunks < (int64_t)kDeepChunks ? max_chunks : (int64_t)kDeepChunks);
+    chunk_bwd_kernel<<<dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
-        lin_step(W), lin_step(H), state, chunk_state,
-        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile),
-        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + max_chunks,
-        reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile) + 2 * (size_t)max_chunks,
-        d_rgb, partials, prezeroed);
+        lin_step(W), lin_step(H), state, chunk_state, meta, meta + max_chunks, meta + 2 * (size_t)max_chunks,
+        d_rgb, partials, prezeroed, (uint32_t)max_chunks, reinterpret_cast<const float*>(meta + tail_mid_offset((size_t)max_chunks)));
     GSX_LAUNCH_CHECK();
     return GSX_OK;
+}
+
+GSX_API int64_t gsx_chunk_state_floats(int64_t max_chunks)
+{
+    if (max_chunks < 0 || max_chunks > (int64_t)kItemChunk) return GSX_E_RANGE;
+    return (int64_t)GSX_CHUNK_STATE_FLOATS(max_chunks > 0 ? max_chunks : 1);
 }
 
 GSX_API const char* gsx_strerror(int status)

@@ -244,7 +244,7 @@ def composite_forward(rec, ranks_sorted, ranges, chunk_base, n, H, W, D, want_de
     dmap = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_depth else None
     state = torch.empty(4, dtype=torch.int32, device=dev)
     max_chunks = int(lib.gsx_max_chunks(D, H, W, _scratch.force_chunk))
-    chunk_state = torch.empty(max(max_chunks, 1) * (L.STATE_WORDS * 256 + 78) + 16, dtype=torch.float32, device=dev)
+    chunk_state = torch.empty(int(L.lib().gsx_chunk_state_floats(max(max_chunks, 1))), dtype=torch.float32, device=dev)
     with _stage("composite_fwd"):
         L.check(lib.gsx_composite_fwd(_ptr(rec), _ptr(ranks_sorted), _ptr(ranges), _ptr(chunk_base), n, H, W,
                                       max_chunks, _ptr(chunk_state), 1 if need_bwd else 0, _ptr(state),
@@ -257,7 +257,7 @@ def _arena_shapes(n, H, W, cap, max_chunks):
     i32, f32 = torch.int32, torch.float32
     return {"order": (i32, (n,)), "rank_of": (i32, (n,)), "rec": (f32, (n, L.REC_FLOATS)), "tt": (i32, (n,)), "offsets": (i32, (n,)),
             "tiles": (i32, (cap,)), "ranks": (i32, (cap,)), "ranges": (i32, (tiles, 2)), "chunk_base": (i32, (tiles + 2,)),
-            "chunk_state": (f32, (max(max_chunks, 1) * (L.STATE_WORDS * 256 + 78) + 16,))}
+            "chunk_state": (f32, (int(L.lib().gsx_chunk_state_floats(max(max_chunks, 1))),))}
 
 
 class ViewState:

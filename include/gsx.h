@@ -44,7 +44,7 @@ extern "C" {
 const char* gsx_strerror(int status);
 int gsx_last_hip_error(void);
 /* ABI version; bumped on any signature change */
-#define GSX_ABI_VERSION 19
+#define GSX_ABI_VERSION 20
 int gsx_abi_version(void);
 
 /* ---- a5-a8 + sort key: replaces _project_positions, _project_scales,
@@ -153,12 +153,16 @@ int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box /* from gsx_bui
 /* upper bound on the chunk count of any view of at most D instances (max over the chunk sizes the device may pick, or
  * D / chunk_force) + min(D, n_tiles).  The caller sizes
  * chunk_state with it: GSX_CHUNK_STATE_FLOATS(max_chunks) floats (the tail holds the per-chunk
- * meta words and the backward work lists, gsx_constants.h). */
+ * meta words, the backward work lists and a shallow view's mid-chunk states, gsx_constants.h). */
 int64_t gsx_max_chunks(int64_t D, int32_t H, int32_t W, int32_t chunk_force);
+/* floats of the chunk_state buffer for that bound (GSX_CHUNK_STATE_FLOATS of gsx_constants.h, for callers that cannot
+ * evaluate a C macro); negative GSX_E_* when max_chunks is out of range. */
+int64_t gsx_chunk_state_floats(int64_t max_chunks);
 
 /* ---- compositing: replaces the inner loop of _render_chunk (:118-148).  A tile's depth-ordered
- * list is cut into chunks of 64 / 128 / GSX_CHUNK instances (chunk_base[n_tiles + 1]); one wave64 composites one chunk for the whole
- * 16x16 tile (4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
+ * list is cut into chunks of 64 / 128 / GSX_CHUNK instances (chunk_base[n_tiles + 1]); a workgroup of four wave64 composites
+ * one chunk for the whole 16x16 tile, a quarter of the chunk per wave, merged in order through LDS (one wave per chunk in a
+ * deep view; 4 pixels per lane, splat records staged through LDS); a per-tile pass then combines
  * the chunks (compositing is associative), writes the image and -- with need_bwd -- each chunk's dark-quadrant
  * bytes and the backward's work lists.  Enqueues, in order: (only when max_chunks could hold a deep view, 20480
  * chunks and more: the level-order table and the header pass of the forward occlusion skipping -- launches that return at
@@ -214,8 +218,9 @@ int gsx_view_forward(const float* positions, const float* scales, const float* r
  * Occlusion cut: an 8x8 quadrant whose pixels all enter a chunk with |T| < 2^-(GSX_CUT_LOG2 + g), g = the chunk's
  * bound on the growth of |T| in bits (gsx_constants.h; 0 unless an opacity lies outside [0, 2]), is masked out for
  * that chunk: all its weights T*alpha stay below 2^-23, like the pairs the footprint cut drops.  A chunk with four
- * dark quadrants gets zero rows without evaluating a pair.  gridDim = max_chunks: the chunks are taken from the
- * work lists the forward's combine pass left in chunk_state (costliest first).
+ * dark quadrants gets zero rows without evaluating a pair.  The work items are taken from the lists the forward's combine
+ * pass left in chunk_state (costliest first): a chunk, or -- in a shallow view, whose chunk pass also left each chunk's
+ * mid-chunk state -- half a chunk.
  *   partials: >= D rows of 9 floats.
  *   n_rows: the view's instance count D as the caller knows it (rows 0 .. n_rows - 1 exist and are this view's), or 0.
  *       From GSX_PREZERO_ROWS on the call zero-fills those rows in one pass up front and occluded chunks write nothing

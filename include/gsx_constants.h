@@ -74,8 +74,9 @@
  * (alpha = o * G, G <= 1: |1 - alpha| <= 1 for o in [0, 2], so g = 0 for ordinary opacities; GSX_META_GROWTH_MAX =
  * unbounded).  dark bytes (written by the combine pass): byte w = 1 when every pixel of 8x8 quadrant w enters the
  * chunk with |T| < 2^-(GSX_CUT_LOG2 + g) -- the backward masks such a quadrant out.  Behind them: 16 u32 counters
- * and 2 x 5 work lists of max_chunks chunk ids each (the backward's work items by expected cost, costliest first,
- * fully occluded chunks last; the second set is used after a global early exit). */
+ * and 2 x 5 work lists of 2 x max_chunks entries each (the backward's work items by expected cost, costliest first,
+ * fully occluded chunks last; the second set is used after a global early exit).  An entry is a chunk id; bit 31 marks
+ * the FIRST half of a chunk cut in two, bit 30 the second half (shallow views, see GSX_MID_WORDS below). */
 #define GSX_META_COST_SHIFT 8
 #define GSX_META_COST_MASK 0xFFFFu
 #define GSX_META_GROWTH_SHIFT 24
@@ -83,9 +84,18 @@
 /* Behind the work lists: what the chunk pass PUBLISHES per chunk when it is done -- a header word (the chunk's bound on the
  * growth of |T| in quarter-bits, or "unbounded") and 64 payload words (per pixel, one byte: floor(-4 log2 |T_local|) + 65) --
  * and the level-order dispatch table of the chunk pass (gsx_composite.hip, "Forward occlusion skipping").
- * floats the chunk-state buffer needs for max_chunks chunks: states, then per chunk 1 flag word, 1 of dark bytes, 10 of work
- * lists (+ 16 counters), 1 header, 1 table entry, 64 of payload */
-#define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + 78) + 16)
+ * Behind those: the MID-CHUNK states of a shallow view (fewer than GSX_DEEP_CHUNKS chunks; round 3): per chunk and pixel
+ * GSX_MID_WORDS floats -- local colour (3) and local transmittance (mantissa, exponent) of the chunk's SECOND half -- from
+ * which the backward starts the chunk's first half on a wave of its own (two work items per chunk: half the latency of
+ * the longest item, which is what bounded the backward's tail).  Room for min(max_chunks, GSX_DEEP_CHUNKS) chunks.
+ * The work lists hold 2 x max_chunks entries each (a chunk in two halves is two entries).
+ * floats the chunk-state buffer needs for max_chunks chunks: states, then per chunk 1 flag word, 1 of dark bytes, 20 of work
+ * lists (+ 16 counters), 1 header, 1 table entry, 64 of payload; then the mid-chunk states */
+#define GSX_DEEP_CHUNKS 20480
+#define GSX_MID_WORDS 5
+#define GSX_CHUNK_TAIL_WORDS 88
+#define GSX_CHUNK_STATE_FLOATS(max_chunks) ((size_t)(max_chunks) * (GSX_STATE_WORDS * 256 + GSX_CHUNK_TAIL_WORDS) + 16 + \
+    (size_t)((max_chunks) < GSX_DEEP_CHUNKS ? (max_chunks) : GSX_DEEP_CHUNKS) * GSX_MID_WORDS * 256)
 
 /* the depth sort may skip its last pass (key bits 24..31) while those bits are the same for every Gaussian; the sort
  * counts the keys that break that assumption (gsx_sort_pairs_u32's check_bit) */

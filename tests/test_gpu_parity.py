@@ -430,7 +430,7 @@ def _chunk_tail(t):
     mc = t["max_chunks"]
     nch = int(_u32(t["chunk_base"])[-2])
     tail = t["chunk_state"][mc * 8 * 256:].view(torch.int32)
-    h0 = 2 * mc + 16 + 10 * mc
+    h0 = 2 * mc + 16 + 20 * mc
     dark = tail[mc:mc + nch].cpu().numpy().view(np.uint8).reshape(nch, 4)
     hdr = tail[h0:h0 + nch].cpu().numpy().view(np.uint32)
     pay0 = tail[h0 + 2 * mc:h0 + 2 * mc + 64 * nch].view(-1, 64)[:, 0].cpu().numpy().view(np.uint32)

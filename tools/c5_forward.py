@@ -22,7 +22,7 @@ for v in views:
     mc = vs.max_chunks
     tail = vs.chunk_state[mc * L.STATE_WORDS * 256:].view(torch.int32)
     nch = int(vs.chunk_base.cpu().numpy().view(np.uint32)[-2])
-    h0 = 2 * mc + 16 + 10 * mc
+    h0 = 2 * mc + 16 + 20 * mc
     hdr = tail[h0:h0 + nch].cpu().numpy().view(np.uint32)
     pay0 = tail[h0 + 2 * mc: h0 + 2 * mc + 64 * nch].view(-1, 64)[:, 0].cpu().numpy().view(np.uint32)
     db = tail[mc:mc + nch].cpu().numpy().view(np.uint8).reshape(nch, 4)

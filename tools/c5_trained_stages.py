@@ -38,7 +38,7 @@ def stages(tag):
     tail = vs.chunk_state[mc * L.STATE_WORDS * 256:].view(torch.int32)
     nch = int(vs.chunk_base.cpu().numpy().view(np.uint32)[-2])
     meta = tail[:nch].cpu().numpy().view(np.uint32)
-    h0 = 2 * mc + 16 + 10 * mc
+    h0 = 2 * mc + 16 + 20 * mc
     hdr = tail[h0:h0 + nch].cpu().numpy().view(np.uint32)
     pay0 = tail[h0 + 2 * mc: h0 + 2 * mc + 64 * nch].view(nch, 64)[:, 0].cpu().numpy().view(np.uint32)
     skipped = int((pay0 == 0).sum())

@@ -23,7 +23,7 @@ for v in views:
     tail = cs[mc * L.STATE_WORDS * 256:].view(torch.int32).cpu().numpy().view(np.uint32)
     nch = int(vs.chunk_base.cpu().numpy().view(np.uint32)[-2])
     dark = tail[mc:mc + nch]
-    h0 = 2 * mc + 16 + 10 * mc
+    h0 = 2 * mc + 16 + 20 * mc
     hdr = tail[h0:h0 + nch]
     pay = tail[h0 + 2 * mc: h0 + 2 * mc + 64 * nch].reshape(nch, 64)
     skipped = int((pay[:, 0] == 0).sum()); unpublished = 0
