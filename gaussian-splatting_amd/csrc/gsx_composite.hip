@@ -938,8 +938,10 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         // training view of the bench scene -- never reach the search, whatever their opacities do.
         const bool unsat = inside && (A <= GSX_SAT_ALPHA - 1e-5f) && !tile_nonmono;
         // thousands of tiles raise the same flag: look before the atomic (4096 same-address atomics serialise in L2)
-        if (__syncthreads_or(unsat) && threadIdx.x == 0 &&
-            __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(state + 1, 1u);
+        // (bit 1: some tile holds a splat that can take A down -- the exit search then needs its rounds)
+        const uint32_t raise = (__syncthreads_or(unsat) ? 1u : 0u) | (__syncthreads_or(tile_nonmono) ? 2u : 0u);      // (a wave past its dark point saw fewer flags)
+        if (raise && threadIdx.x == 0 &&
+            (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & raise) != raise) atomicOr(state + 1, raise);
     }
     if (need_bwd && c1 > c0) {
         float B0 = 0.f, B1 = 0.f, B2 = 0.f;
@@ -992,10 +994,12 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 // saturated, so f_p(k) <= k* for k <= k*), and a fixpoint is a rank at which all pixels are saturated: it is k*.  One pass
 // over the lists per round, a grid barrier between rounds (the grid is at most kSatBlocks workgroups, all resident; every
 // workgroup arrives at every barrier, and the rounds end because k grows until it stands or some pixel reports "never");
-// the monotone case takes two rounds (the second confirms).  state[2] = the running maximum (monotone: no reset between
+// a view without a non-monotone splat (state[1] bit 1 clear: the combine pass raises it from the chunks' flags) takes the
+// one pass it always took, on the whole grid, without a barrier.  state[2] = the running maximum (monotone: no reset between
 // rounds), state[3] = barrier arrivals; both zeroed with state[0..1] by pass 0.
 // ------------------------------------------------------------------------------------------
-constexpr int kSatBlocks = 256;
+constexpr int kSatBlocks = 512;           // workgroups that take part in the rounds of a non-monotone view: a quarter of what the chip holds
+                                          // resident (8 of these per CU), so that up to four streams' searches can spin side by side
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state)
@@ -1004,14 +1008,20 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     __shared__ uint32_t s_rank[kBlock];
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_k;
-    if (state[1] != 0u) {                    // some pixel never saturates: no early exit (uniform over the grid: written by pass 0)
+    const uint32_t flags = state[1];          // (uniform over the grid: written by pass 0's combine launch)
+    if (flags & 1u) {                        // some pixel never saturates: no early exit
         if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = GSX_RANK_NONE;
         return;
     }
+    // A view without a non-monotone splat needs ONE pass and no barrier: every workgroup adds its maximum to state[0]
+    // (zeroed by pass 0) and is done.  Otherwise the rounds below, on the first kSatBlocks workgroups only.
+    const bool monotone = (flags & 2u) == 0u;
+    const uint32_t n_blocks = monotone ? gridDim.x : min(gridDim.x, (uint32_t)kSatBlocks);
+    if (blockIdx.x >= n_blocks) return;
     uint32_t k_cur = 0u, result;
     for (uint32_t round = 1u; ; round++) {
         uint32_t mine = 0u;                  // max of f_p(k_cur) over this thread's pixels (GSX_RANK_NONE = never: the largest value)
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
             const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
             const bool inside = x < W && y < H;
@@ -1050,11 +1060,15 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
         __syncthreads();
+        if (monotone) {                      // (uniform) the first crossings' maximum is the exit rank
+            if (threadIdx.x == 0) atomicMax(state, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            return;
+        }
         if (threadIdx.x == 0) {
             atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
             // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
             __hip_atomic_fetch_add(state + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t target = round * gridDim.x;
+            const uint32_t target = round * n_blocks;
             while (__hip_atomic_load(state + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
             s_k = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1356,8 +1370,7 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
-    // (its grid barrier needs every workgroup resident: at most one per CU of the smallest part this runs on)
-    saturation_rank_kernel<<<dim3((unsigned)(n_tiles < kSatBlocks ? n_tiles : kSatBlocks)), dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
+    saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);

@@ -170,8 +170,9 @@ int64_t gsx_chunk_state_floats(int64_t max_chunks);
  * combine pass, exact early-exit search (only does work when every pixel saturated: the
  * reference's global exit, :147), and a second chunk + combine pass that only does work when the
  * exit fired before the last Gaussian.
- *   state (4 x u32, out): state[0] = exit rank k* (GSX_RANK_NONE: no exit), state[1] = 1 if some
- *       pixel is unsaturated.  Ranks 0..k* are composited.
+ *   state (4 x u32, out): state[0] = exit rank k* (GSX_RANK_NONE: no exit); state[1] bit 0 = some pixel can never have
+ *       been saturated (no exit), bit 1 = some tile holds a splat with alpha outside [0, 1] (the exit search then iterates:
+ *       the accumulated alpha is not monotone); state[2..3] are the search's scratch.  Ranks 0..k* are composited.
  *   chunk_state: GSX_CHUNK_STATE_FLOATS(max_chunks) floats; with need_bwd = 1 it is left holding
  *       what gsx_composite_bwd needs (per chunk and pixel: colour behind the chunk, transmittance
  *       at its end).
