@@ -325,6 +325,250 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same one-pass sort for images of up to 8192 tiles (round 3; 1920 x 1080 = 8160: BASELINE config 5 used to take the
+// generic path -- two 8-bit passes of three launches, a launch of binary searches, a scan: the largest stage that was
+// left of a config-5 step).  A 13-bit digit doubles the counters: 8 waves x 8192 u16 = 128 KB is what fits, so the
+// workgroup is 512 threads (8 waves), each thread holds up to 32 keys (16384 keys per workgroup, as in the 12-bit form:
+// the histogram table costs 2 B per key), and what the 12-bit form keeps BESIDE the counters -- per tile the position of
+// its first key inside the workgroup and the global base -- moves: the first goes INTO the counters (added to every
+// wave's prefix), the second into the counters' space once they are dead (next to the staged keys and values: 64 + 32 + 32
+// KB = the 128 KB exactly).  Thread t owns tiles 16 t .. 16 t + 15.
+// ------------------------------------------------------------------------------------------
+constexpr int kWsBits = 13, kWsDigits = 1 << kWsBits;
+constexpr int kWsThreads = 512, kWsWaves = kWsThreads / 64;
+constexpr int kWsItems = 32;
+constexpr int kWsOwn = kWsDigits / kWsThreads;               // 16 tiles per thread
+__device__ __host__ __forceinline__ int ws_items(int64_t n)
+{
+    const int64_t it = (n + (int64_t)kTsCus * kWsThreads - 1) / ((int64_t)kTsCus * kWsThreads);
+    return it < 2 ? 2 : (it > kWsItems ? kWsItems : (int)it);
+}
+
+__global__ __launch_bounds__(kWsThreads) void wtile_hist_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ total_dev,
+                                                                int64_t capacity, int n_tiles, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_hist[kWsDigits];
+    const int64_t n = ts_count(total_dev, capacity);
+    const int items = ws_items(n);
+    const int64_t base = (int64_t)blockIdx.x * items * kWsThreads;
+    if (base >= n) return;
+    for (int d = threadIdx.x; d < n_tiles; d += kWsThreads) s_hist[d] = 0;
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < kWsItems; k++) {
+        const int64_t i = base + k * kWsThreads + threadIdx.x;
+        if (k < items && i < n) atomicAdd(&s_hist[keys[i] & (kWsDigits - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * kWsDigits;
+    for (int d = threadIdx.x; d < n_tiles; d += kWsThreads) row[d] = s_hist[d];
+}
+
+// column scan of the wide table: as tile_colscan_kernel, rows of kWsDigits words, workgroups of ws_items(n) * 512 keys
+__global__ __launch_bounds__(kTsThreads) void wtile_colscan_kernel(uint32_t* __restrict__ hist, const uint64_t* __restrict__ total_dev,
+                                                                   int64_t capacity, int n_tiles, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_seg[kTsWaves][kTsSegDigits];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int d = blockIdx.x * kTsSegDigits + lane;
+    const int64_t n = ts_count(total_dev, capacity);
+    const int64_t tile = (int64_t)ws_items(n) * kWsThreads;
+    const int nb = (int)((n + tile - 1) / tile);
+    const int per = (nb + kTsWaves - 1) / kTsWaves;
+    const int r0 = min(seg * per, nb), r1 = min(r0 + per, nb);
+    const bool live = d < n_tiles;
+    uint32_t sum = 0;
+    if (live) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const uint32_t a = hist[(size_t)r * kWsDigits + d], b = hist[(size_t)(r + 1) * kWsDigits + d];
+            const uint32_t c = hist[(size_t)(r + 2) * kWsDigits + d], e = hist[(size_t)(r + 3) * kWsDigits + d];
+            sum += (a + b) + (c + e);
+        }
+        for (; r < r1; r++) sum += hist[(size_t)r * kWsDigits + d];
+    }
+    s_seg[seg][lane] = sum;
+    __syncthreads();
+    if (!live) return;
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < kTsWaves; s2++) { const uint32_t v = s_seg[s2][lane]; if (s2 < seg) run += v; tot += v; }
+    if (seg == 0) totals[d] = tot;
+    for (int r = r0; r < r1; r++) {
+        uint32_t* cell = hist + (size_t)r * kWsDigits + d;
+        const uint32_t v = *cell; *cell = run; run += v;
+    }
+}
+
+// exclusive scan of one value per thread over a 512-thread workgroup
+__device__ __forceinline__ uint32_t block512_excl_scan(uint32_t v, uint32_t* s_wave /*[8]*/, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWsWaves; w++) { const uint32_t x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kWsThreads) void wtile_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                   const uint64_t* __restrict__ total_dev, int64_t capacity, int n_tiles,
+                                                                   const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
+                                                                   int chunk_force, uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base)
+{
+    // per-wave digit counts; then per wave and tile the position of the wave's first key of that tile inside the workgroup's
+    // tile-sorted order; then (dead) the staged values, keys and the tiles' global bases
+    __shared__ __align__(16) uint16_t s_cnt[kWsWaves][kWsDigits];           // 128 KB
+    __shared__ uint32_t s_scan[kWsWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = ts_count(total_dev, capacity);
+    const int items = ws_items(n);
+    const int64_t base = (int64_t)blockIdx.x * items * kWsThreads;
+    const bool active = base < n;
+    if (!active && blockIdx.x != 0) return;
+    const int64_t left = n - base;
+    const uint32_t here = active ? (uint32_t)(left < (int64_t)items * kWsThreads ? left : (int64_t)items * kWsThreads) : 0u;
+    const uint32_t* kin = keys_in + (active ? base : 0);
+    const uint32_t* vin = vals_in + (active ? base : 0);
+    const uint32_t wlane = (uint32_t)(wave * items * 64 + lane);        // each wave owns a contiguous run of keys
+    uint32_t key[kWsItems];
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++) {
+        const uint32_t li = wlane + k * 64;
+        key[k] = (k < items && li < here) ? (kin[li] & (kWsDigits - 1)) : 0u;
+    }
+    // tile bases = exclusive scan of the column totals; thread t owns tiles 16 t .. 16 t + 15
+    uint32_t gb[kWsOwn];                                                // first global slot of this workgroup's keys of my tiles
+    {
+        uint32_t tv[kWsOwn], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kWsOwn; i++) { const int d = kWsOwn * tid + i; tv[i] = d < n_tiles ? totals[d] : 0u; sum += tv[i]; }
+        uint32_t tot;
+        uint32_t run = block512_excl_scan(sum, s_scan, &tot);
+        if (blockIdx.x == 0) {
+            // ranges[t] = [first, last), chunk_base = scan of ceil(len / chunk size): what ranges_kernel and the chunk-table scan do
+            const uint32_t ch = chunk_size_for((uint64_t)n, chunk_force);
+            uint32_t csum = 0, r2 = run;
+#pragma unroll
+            for (int i = 0; i < kWsOwn; i++) {
+                const int d = kWsOwn * tid + i;
+                if (d < n_tiles) { ranges[2 * d] = r2; ranges[2 * d + 1] = r2 + tv[i]; csum += (tv[i] + ch - 1) / ch; }
+                r2 += tv[i];
+            }
+            uint32_t ctot;
+            uint32_t cex = block512_excl_scan(csum, s_scan, &ctot);
+#pragma unroll
+            for (int i = 0; i < kWsOwn; i++) {
+                const int d = kWsOwn * tid + i;
+                if (d < n_tiles) { chunk_base[d] = cex; cex += (tv[i] + ch - 1) / ch; }
+            }
+            if (tid == 0) { chunk_base[n_tiles] = ctot; chunk_base[n_tiles + 1] = ch; }
+            if (!active) return;
+        }
+        const uint32_t* prow = hist_scanned + (size_t)blockIdx.x * kWsDigits;
+#pragma unroll
+        for (int i = 0; i < kWsOwn; i++) { const int d = kWsOwn * tid + i; gb[i] = run + (d < n_tiles ? prow[d] : 0u); run += tv[i]; }
+    }
+    {
+        uint4* z = reinterpret_cast<uint4*>(&s_cnt[0][0]);
+        constexpr int kVec = kWsWaves * kWsDigits * 2 / 16;
+        for (int i = tid; i < kVec; i += kWsThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    uint16_t* cnt = s_cnt[wave];
+    // from here key[k] also carries the key's position: tile id in bits 0..12, position (< 16384) above
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++) {
+        if (k < items) {                                                // uniform
+            const bool valid = wlane + k * 64 < here;
+            const uint32_t d = key[k];
+            uint32_t rank, count;
+            wave_match_rank<kWsBits>(d, valid, rank, count);
+            const uint32_t old = cnt[d];                               // every lane reads before the leader writes
+            if (valid && rank == 0) cnt[d] = (uint16_t)(old + count);
+            key[k] = d | ((old + rank) << kWsBits);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t val[kWsItems];
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++) {
+        const uint32_t li = wlane + k * 64;
+        val[k] = (k < items && li < here) ? vin[li] : 0u;
+    }
+    __syncthreads();
+    // per tile: total over the 8 waves (pass A, read only), the tiles' first positions inside the workgroup (exclusive scan in
+    // tile order), then each wave's entry becomes first position + the counts of the waves before it (pass B).  A thread's 16
+    // tiles are two uint4 of packed u16 per wave row; sums stay below 2^15, so the packed adds never carry into a neighbour.
+    uint4* c4 = reinterpret_cast<uint4*>(&s_cnt[0][0]);
+    constexpr int kRow4 = kWsDigits * 2 / 16;                           // uint4 per wave row
+    uint32_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // 16 packed u16 totals
+#pragma unroll
+    for (int w = 0; w < kWsWaves; w++) {
+        const uint4 a = c4[w * kRow4 + 2 * tid], b = c4[w * kRow4 + 2 * tid + 1];
+        tsum[0] += a.x; tsum[1] += a.y; tsum[2] += a.z; tsum[3] += a.w; tsum[4] += b.x; tsum[5] += b.y; tsum[6] += b.z; tsum[7] += b.w;
+    }
+    uint32_t mysum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) mysum += (tsum[i] & 0xffffu) + (tsum[i] >> 16);
+    uint32_t ltot;
+    uint32_t lrun = block512_excl_scan(mysum, s_scan, &ltot);
+    uint32_t lstart[8];                                                 // 16 packed u16 first positions
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t lo = lrun; lrun += tsum[i] & 0xffffu;
+        const uint32_t hi = lrun; lrun += tsum[i] >> 16;
+        lstart[i] = lo | (hi << 16);
+        gb[2 * i] -= lo; gb[2 * i + 1] -= hi;                           // global slot of local position 0 of the tile
+    }
+    {
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = lstart[i];
+#pragma unroll
+        for (int w = 0; w < kWsWaves; w++) {
+            const uint4 a = c4[w * kRow4 + 2 * tid], b = c4[w * kRow4 + 2 * tid + 1];
+            c4[w * kRow4 + 2 * tid] = make_uint4(r[0], r[1], r[2], r[3]);
+            c4[w * kRow4 + 2 * tid + 1] = make_uint4(r[4], r[5], r[6], r[7]);
+            r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w; r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++)
+        if (k < items) { const uint32_t d = key[k] & (kWsDigits - 1); key[k] += (uint32_t)cnt[d] << kWsBits; }
+    __syncthreads();                                                    // the counters are dead: their LDS stages values, keys and bases
+    uint32_t* s_val = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);        // 16384 x 4 B = 64 KB
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(s_val + kWsThreads * kWsItems);      // 16384 x 2 B = 32 KB
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_key + kWsThreads * kWsItems);     // 8192 x 4 B = 32 KB
+#pragma unroll
+    for (int i = 0; i < kWsOwn; i++) s_base[kWsOwn * tid + i] = gb[i];
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++) {
+        const uint32_t li = wlane + k * 64;
+        if (k < items && li < here) { const uint32_t pos = key[k] >> kWsBits; s_val[pos] = val[k]; s_key[pos] = (uint16_t)(key[k] & (kWsDigits - 1)); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWsItems; k++) {
+        const uint32_t i = (uint32_t)(k * kWsThreads + tid);
+        if (k < items && i < here) {
+            const uint32_t d = s_key[i];
+            const uint32_t dst = s_base[d] + i;
+            keys_out[dst] = d;
+            vals_out[dst] = s_val[i];
+        }
+    }
+}
+
 // workgroups to launch for `capacity` instances: the device picks the keys per workgroup from the real count
 static int64_t tile_sort_blocks(int64_t capacity)
 {
@@ -336,6 +580,16 @@ static size_t tile_sort_ws_bytes(int64_t capacity)
     int64_t nb = tile_sort_blocks(capacity);
     if (nb < kTsCus) nb = kTsCus;
     return align_up((size_t)nb * kTsDigits * 4) + align_up((size_t)kTsDigits * 4);
+}
+static int64_t wtile_sort_blocks(int64_t capacity)
+{
+    return ceil_div(capacity > 0 ? capacity : 1, (int64_t)ws_items(capacity) * kWsThreads);
+}
+static size_t wtile_sort_ws_bytes(int64_t capacity)
+{
+    int64_t nb = wtile_sort_blocks(capacity);
+    if (nb < kTsCus) nb = kTsCus;
+    return align_up((size_t)nb * kWsDigits * 4) + align_up((size_t)kWsDigits * 4);
 }
 
 }  // namespace gsx
@@ -350,7 +604,8 @@ GSX_API size_t gsx_bin_workspace_bytes(int32_t N, int64_t capacity)
     size_t a = gsx_scan_workspace_bytes(N > 0 ? N : 1);
     size_t b = sort_ws_bytes_internal(capacity > 0 ? capacity : 1);
     size_t c = chunk_scan_ws_bytes();
-    size_t t = tile_sort_ws_bytes(capacity);
+    size_t t = tile_sort_ws_bytes(capacity), t13 = wtile_sort_ws_bytes(capacity);
+    if (t13 > t) t = t13;
     size_t m = a > b ? a : b;
     if (t > m) m = t;
     return 256 + (m > c ? m : c);
@@ -424,6 +679,24 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box, const 
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
         tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
                                                                     hist, totals, chunk_force, ranges, chunk_base);
+        GSX_LAUNCH_CHECK();
+        return GSX_OK;
+    }
+    if (n_tiles <= kWsDigits) {
+        // one 13-bit pass (a 1080p image: 8160 tiles): as above with 512-thread workgroups of up to 16384 keys
+        int64_t nbl = wtile_sort_blocks(capacity);
+        const int64_t small = ceil_div(capacity, 2 * kWsThreads);
+        if (nbl < kTsCus) nbl = small < kTsCus ? small : kTsCus;
+        const unsigned nb = (unsigned)nbl;
+        uint32_t* hist = (uint32_t*)sub_ws;
+        uint32_t* totals = (uint32_t*)((char*)sub_ws + align_up((size_t)nb * kWsDigits * 4));
+        if (N > 0) {
+            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
+            wtile_hist_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
+        }
+        wtile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
+        wtile_scatter_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
+                                                                     hist, totals, chunk_force, ranges, chunk_base);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }

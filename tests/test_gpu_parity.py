@@ -221,8 +221,10 @@ CASES = {
     "c3_50000_320x320_orbit": lambda: (synth_scene(50000, 5, 0.001, 0.005), orbit_pose(15), 320, 320),
     "c5_6000_480x270_ties": lambda: (synth_scene(6000, 8, 0.01, 0.1, zq=64.0), pose_tz(2.0), 270, 480),
     "opacity_out_of_range": lambda: (synth_scene(3000, 9, 0.005, 0.03, o_lo=-0.5, o_hi=1.5), pose_tz(2.0), 96, 128),
-    # 66 x 65 = 4290 tiles: beyond the one-pass 12-bit tile sort, i.e. the generic two-pass radix path + ranges kernel
+    # 66 x 65 = 4290 tiles: beyond the one-pass 12-bit tile sort: the 13-bit one-pass form (512-thread workgroups, round 3)
     "more_than_4096_tiles_1056x1040": lambda: (synth_scene(4000, 12, 0.004, 0.03), pose_tz(2.0), 1040, 1056),
+    # 129 x 65 = 8385 tiles: beyond that one too, i.e. the generic two-pass radix path + ranges kernel + chunk-table scan
+    "more_than_8192_tiles_2064x1040": lambda: (synth_scene(4000, 13, 0.004, 0.03), pose_tz(2.0), 1040, 2064),
     # every pixel saturates after a few screen-sized opaque splats: the reference's global early exit fires (n_composited < N)
     # on 4096 tiles and > 2048 chunks, i.e. the exit search and the second compositing pass walk their small grids with a stride
     "global_exit_4096_tiles": lambda: (synth_scene(400, 21, 1.0, 2.0, o_lo=0.9, o_hi=1.0), pose_tz(2.0), 1024, 1024),
@@ -649,7 +651,7 @@ FULL_SIZE = {
     "c2_100k_800x800": lambda: (synth_scene(100_000, 2, 0.002, 0.01), pose_tz(2.0), 800, 800),
     # config 4's per-GPU share: 3 M Gaussians on 1024^2, orbit view 7 (one of its eight views)
     "c4_3M_orbit_view7": lambda: (synth_scene(3_000_000, 6, 0.001, 0.005), orbit_pose(7), 1024, 1024),
-    # config 5's image (1920x1080: 8160 tiles, the generic two-pass tile sort), splat sizes and quantised depths at 1/1000 of
+    # config 5's image (1920x1080: 8160 tiles, the 13-bit one-pass tile sort), splat sizes and quantised depths at 1/1000 of
     # its Gaussian count (the oracle's time goes with the instance count: millions here, billions at 6 M)
     "c5_6k_1920x1080": lambda: (synth_scene(6_000, 8, 0.01, 0.1, zq=64.0), pose_tz(2.0), 1080, 1920),
 }
@@ -675,7 +677,7 @@ def test_full_size_vs_oracle(dev, O, case):
 
 def test_config5_full_size_properties(dev):
     """BASELINE config 5 AT ITS OWN SIZE: 6 M Gaussians with splats of up to ~100 px and depths quantised to 2^-6 (ties) on
-    1920x1080 = 8160 tiles (the generic two-pass tile sort), orbit view 1: ~39 M (tile, Gaussian) instances.  The oracle
+    1920x1080 = 8160 tiles (the 13-bit one-pass tile sort), orbit view 1: ~39 M (tile, Gaussian) instances.  The oracle
     would need minutes here, so the bar is the size-independent properties (as test_full_size_properties for config 3):
     a permutation in descending depth with ties by index, strictly sorted unique 64-bit keys, ranges that partition [0, D),
     instances inside their Gaussian's box, a finite image, bitwise determinism of image and gradients, and the module
