@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--no-fused-step", action="store_true",
                     help="keep the trainer step on the modular path (module forward, autograd, optimizer.step()) instead of the "
                          "one-call gsx_train_step that train_step() uses for the plain single-GPU case; same kernels, same bits")
+    ap.add_argument("--no-inference-extra", action="store_true",
+                    help="skip the informational forward-only orbit pass behind the timed region (profiling runs: its two-stream "
+                         "overlap inflates the per-kernel averages of a kernel trace)")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused HIP clip+Adam step")
     args = ap.parse_args()
@@ -383,7 +386,7 @@ def main():
 
     # informational, N = 1: BASELINE config 3 read literally (forward-only orbit rendering) next to the headline
     inference = None
-    if world == 1 and not args.inference:
+    if world == 1 and not args.inference and not args.no_inference_extra:
         idx = torch.arange(N_VIEWS, device=dev)
         model.render_frames(poses[idx], (H, W)); torch.cuda.synchronize()
         t1 = time.perf_counter()

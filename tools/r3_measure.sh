@@ -5,7 +5,7 @@ tag=${1:-r3}
 R=/root/repo/gpurun_out
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --steps 60 --warmup 5 --no-cpu-baseline"
+B="python3 /root/repo/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-inference-extra"
 timeout -k 10 120 /root/repo/tools/valu_issue_rate.bin > $R/${tag}_valu_issue_rate.txt 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/prof_$tag -o $tag --output-format csv -- $B > $R/prof_$tag.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS -d $R/pmc_${tag}_sq1 -o s1 --output-format csv -- $B > $R/pmc_${tag}_sq1.log 2>&1 &&
