@@ -50,7 +50,7 @@ PMC_FILE = os.path.join("profiles", "r3_pmc_hbm_traffic.json")
 SQ_FILE = os.path.join("profiles", "r3_pmc_sq_counters.json")
 # stage -> EXACT name (as tools/pmc_traffic.py writes it: arguments stripped) of the kernel whose PMC traffic (separate
 # rocprofv3 --pmc passes on the final tree) belongs to it
-STAGE_KERNEL = {"composite_bwd": "gsx::chunk_bwd_kernel", "composite_fwd": "gsx::chunk_fwd_kernel<false, false, false>",
+STAGE_KERNEL = {"composite_bwd": "gsx::chunk_bwd_kernel", "composite_fwd": "gsx::chunk_fwd_wg_kernel<false>",
                 "preprocess_bwd": "gsx::preprocess_bwd_kernel", "build_records": "gsx::build_records_kernel",
                 "project_fwd": "gsx::project_fwd_kernel"}
 N_VIEWS = 60
