@@ -776,8 +776,8 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
 // local colour by the colour BEHIND it (per unit transmittance at the chunk's end).
 // state[1] is raised if some pixel is clearly not saturated (the global early exit cannot fire).
 // ------------------------------------------------------------------------------------------
-// DEEP: as for the chunk pass -- the instantiation without it is the shallow views' (no rule, no payload, no header: the
-// bench scene's kernel), the one with it the deep views' and pass 1's; in pass 0 the one that does not apply returns at once.
+// DEEP: as for the chunk pass.  Instantiated with it only since round 3: the deep views' pass 0 and every view's pass 1
+// (after a global early exit); a shallow view's pass 0 is tile_list_kernel + tile_combine_par_kernel below.
 template <bool PASS1, bool DEPTH, bool DEEP>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
@@ -957,17 +957,22 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
         }
         for (uint32_t ce = cbl; ce > c0; ce -= kCombineBatch) {                          // earlier batches: full, reloaded
             // dark by the rule is dark for good: if the batch's first chunk is, all of it is the identity for this quadrant
-            if (reinterpret_cast<const uint8_t*>(chunk_dark + (ce - c0 >= (uint32_t)kCombineBatch ? ce - kCombineBatch : c0))[threadIdx.x >> 6] == 0x81) continue;
+            // (lane u fetches this quadrant's dark byte of chunk ce - 1 - u: one load per batch, not one in front of every chunk)
+            uint32_t dkb = 0u;
+            if ((threadIdx.x & 63u) < (uint32_t)kCombineBatch)
+                dkb = reinterpret_cast<const uint8_t*>(chunk_dark + (ce - 1u - (threadIdx.x & 63u)))[threadIdx.x >> 6];
+            const uint32_t by_rule = (uint32_t)__builtin_amdgcn_ballot_w64(dkb == 0x81u);
+            if (by_rule & (1u << (kCombineBatch - 1))) continue;
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
-                const uint32_t c = (ce - c0 > (uint32_t)u) ? ce - 1 - u : c0;
+                const uint32_t c = ce - 1 - u;               // (earlier batches are full: ce - c0 >= kCombineBatch)
                 l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
                 l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
                 l4[u] = *state_ptr(chunk_state, c, 4, pix);
             }
 #pragma unroll
             for (int u = 0; u < kCombineBatch; u++) {
-                if (ce - c0 > (uint32_t)u && reinterpret_cast<const uint8_t*>(chunk_dark + (ce - 1 - u))[threadIdx.x >> 6] != 0x81) {   // (dark by the rule: the identity)
+                if (!(by_rule & (1u << u))) {                 // (dark by the rule: the identity)
                     const uint32_t c = ce - 1 - u;
                     const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
                     *state_ptr(chunk_state, c, 0, pix) = B0; *state_ptr(chunk_state, c, 1, pix) = B1; *state_ptr(chunk_state, c, 2, pix) = B2;
@@ -978,6 +983,285 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     }
     if (!PASS1) break;                        // compile-time: pass 0 has no back edge
     __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// F2 for SHALLOW views (pass 0 of a view of fewer than kDeepChunks chunks; round 3): the same results from a workgroup
+// of 1024 threads that takes a tile's chunks 64 at a time, 16 per GROUP of 256 threads (thread = pixel as above, the four
+// groups side by side along the list).  Compositing is associative: every group folds its 16 local results into one
+// (colour, transmittance), the four meet in LDS, and each group then knows what stands in front of it and what comes
+// behind it.  Why: the bench scene puts all of a view's instances on 250-400 of its 4096 tiles, 30-60 chunks each
+// (tools/tile_depth_stats.py), so the kernel above was ~300 workgroups walking three or four dependent batches each --
+// 40 us of memory round trips for the forward scan alone (ablation: tools/ab_kstats.sh) with the chip empty.  Here such a tile
+// is ONE batch: one round trip for the states, one barrier, one reservation in the work lists.
+// Tiles of more than 64 chunks loop (forward, then backward with the states reloaded, as above).
+// ------------------------------------------------------------------------------------------
+// four groups of 256 threads, 12 chunks per group and batch: what 128 registers hold without scratch (with the depth map's
+// sixth word 9 registers go to scratch; the two instantiations must cut the list alike, or the image would depend in its
+// last bit on whether a depth map was asked for)
+constexpr int kParGroups = 4;
+template <bool DEPTH> struct ParShape { static constexpr int U = 12, Batch = kParGroups * U; };
+constexpr int kParGrid = 512;             // workgroups of the combine pass at most (one of 1024 threads fits a CU): beyond that, a stride
+constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (cleared with the counters by the chunk pass)
+constexpr int kListTiles = 16;            // tiles per workgroup of tile_list_kernel
+
+// The tiles that hold something, as a list (order_tab's room: a shallow view has no level-order table), so that the kernel
+// below runs on those alone: the bench scene leaves 3600-3900 of its 4096 tiles empty, and a grid with one workgroup per
+// tile spent most of its time passing empty workgroups through the dispatcher in front of the 250-400 that have work.
+// The empty tiles' pixels are written here (zeros; alpha 0 is "not saturated": an empty tile vetoes the global exit).
+__global__ __launch_bounds__(kBlock) void tile_list_kernel(
+    const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int n_tiles, uint32_t* __restrict__ state,
+    uint32_t* __restrict__ work, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
+{
+    __shared__ uint32_t s_empty;
+    if (chunk_base[n_tiles] >= kDeepChunks) return;                                  // a deep view: tile_combine_kernel does all of it
+    const int t0 = blockIdx.x * kListTiles;
+    if (threadIdx.x < 64u) {
+        const int t = t0 + (int)threadIdx.x;
+        const bool valid = threadIdx.x < (uint32_t)kListTiles && t < n_tiles;
+        const bool holds = valid && chunk_base[t + 1] > chunk_base[t];
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(holds), me = __builtin_amdgcn_ballot_w64(valid && !holds);
+        if (mh) {
+            uint32_t base = 0u;
+            if (threadIdx.x == 0u) base = atomicAdd(work + kWorkNonEmpty, (uint32_t)__popcll(mh));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (holds) list[base + (uint32_t)__popcll(mh & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)t;
+        }
+        if (threadIdx.x == 0u) s_empty = (uint32_t)me;
+    }
+    __syncthreads();
+    uint32_t em = s_empty;            // (the veto of the empty tiles: tile_combine_par_kernel, from the count)
+    const size_t P = (size_t)H * W;
+    while (em) {
+        const int tile = t0 + __builtin_ctz(em);
+        em &= em - 1u;
+        int x, y; pix_xy((int)(threadIdx.x >> 6), (int)(threadIdx.x & 63u), tile % tw, tile / tw, x, y);
+        if (x < W && y < H) {
+            const size_t p = (size_t)y * W + x;
+            rgb[p] = 0.f; rgb[P + p] = 0.f; rgb[2*P + p] = 0.f;
+            alpha[p] = 0.f;
+            if (depth_map) depth_map[p] = 0.f;
+        }
+    }
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
+    const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int need_bwd,
+    uint32_t* __restrict__ state, float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta,
+    uint32_t* __restrict__ chunk_dark, uint32_t* __restrict__ work, uint32_t max_chunks, int n_tiles,
+    float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map, const uint32_t* __restrict__ ranges,
+    const uint32_t* __restrict__ list)
+{
+    constexpr int G = kParGroups, U = ParShape<DEPTH>::U, kParBatch = ParShape<DEPTH>::Batch, NA = DEPTH ? 6 : 5;
+    static_assert(kParBatch <= 64 && G * kBlock <= 1024, "one wave builds a batch's work-list entries, lane = chunk");
+    // per group and pixel: what the group's chunks add (colour 3, depth with DEPTH) and let through (mantissa, exponent)
+    __shared__ float s_agg[G][NA][kPixPerTile];
+    __shared__ uint8_t s_dark[kParBatch][4];
+    if (chunk_base[n_tiles] >= kDeepChunks) return;                                  // the deep instantiation's view
+    const uint32_t n_held = work[kWorkNonEmpty];
+    // alpha = 0 on an empty tile is "not saturated": it vetoes the global exit (one workgroup says so for all of them; a
+    // look-and-raise per empty tile was 3700 reads of one L2 line)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_held < (uint32_t)n_tiles) atomicOr(state + 1, 1u);
+    for (uint32_t item = blockIdx.x; item < n_held; item += gridDim.x) {
+    const int tile = (int)list[item];
+    const uint32_t c0 = chunk_base[tile], c1 = chunk_base[tile + 1];
+    // (group and quadrant are wave-uniform: in scalar registers, so that a chunk's address is a scalar base + the pixel's offset)
+    const int pix = threadIdx.x & (kPixPerTile - 1);
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), quad = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 3u));
+    const uint32_t lane = threadIdx.x & 63u;
+    int x, y; pix_xy(quad, pix & 63, tile % tw, tile / tw, x, y);
+    const bool inside = x < W && y < H;
+    const bool tiny = H < GSX_TILE || W < GSX_TILE;
+    const int cut = GSX_CUT_LOG2_FOR(H, W);
+    // the tile's state in front of the batch at hand: the same bits in every group (same values, same order)
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, m = 1.f; int e = 0;
+    bool nonmono = false;
+    float l0[U], l1[U], l2[U], l3[U], l4[U];
+    uint32_t sb_last = c0;
+    // work-list reservation of the last batch (wave 0), emitted after the backward scan
+    int wl_cls = -1; bool wl_halves = false; uint32_t wl_base = 0u, wl_below = 0u;
+    const uint32_t ch = chunk_base[n_tiles + 1];
+
+    // the states of this group's chunks [g0, g0 + U) (clamped: a group past the list's end loads nothing)
+    auto load_states = [&](uint32_t g0) {
+        if (g0 < c1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = min(g0 + u, c1 - 1u);
+                l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
+                l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
+                l4[u] = *state_ptr(chunk_state, c, 4, pix);
+            }
+        }
+    };
+    // ... folded into one and published (identity for a group past the end)
+    auto publish = [&](uint32_t g0, const float* l5) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, am = 1.f; int ae = 0;
+        if (g0 < c1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (g0 + u < c1) {
+                    const float Tv = ldexpf(am, ae);
+                    a0 += Tv * l0[u]; a1 += Tv * l1[u]; a2 += Tv * l2[u];
+                    if (DEPTH && l5) ad += Tv * l5[u];
+                    am *= l3[u];
+                    ae += __float_as_int(l4[u]);
+                    renorm(am, ae);
+                }
+            }
+        }
+        s_agg[grp][0][pix] = a0; s_agg[grp][1][pix] = a1; s_agg[grp][2][pix] = a2;
+        if (DEPTH) s_agg[grp][3][pix] = ad;
+        s_agg[grp][NA - 2][pix] = am; s_agg[grp][NA - 1][pix] = __int_as_float(ae);
+    };
+    // colour behind this group's last chunk (b) and in front of the whole batch (F), per unit of transmittance there,
+    // from the colour F behind the batch
+    auto behind = [&](float& F0, float& F1, float& F2, float& b0, float& b1, float& b2) {
+#pragma unroll
+        for (int g = G - 1; g >= 0; g--) {
+            if (g == grp) { b0 = F0; b1 = F1; b2 = F2; }
+            const float Tg = ldexpf(s_agg[g][NA - 2][pix], __float_as_int(s_agg[g][NA - 1][pix]));
+            F0 = s_agg[g][0][pix] + Tg * F0; F1 = s_agg[g][1][pix] + Tg * F1; F2 = s_agg[g][2][pix] + Tg * F2;
+        }
+    };
+    // each chunk's local colour replaced by the colour behind it, back to front
+    auto scan_back = [&](uint32_t g0, float b0, float b1, float b2) {
+        if (g0 < c1) {
+#pragma unroll
+            for (int u = U - 1; u >= 0; u--) {
+                const uint32_t c = g0 + u;
+                if (c < c1) {
+                    const float Tl = ldexpf(l3[u], __float_as_int(l4[u]));
+                    *state_ptr(chunk_state, c, 0, pix) = b0; *state_ptr(chunk_state, c, 1, pix) = b1; *state_ptr(chunk_state, c, 2, pix) = b2;
+                    b0 = l0[u] + Tl * b0; b1 = l1[u] + Tl * b1; b2 = l2[u] + Tl * b2;
+                }
+            }
+        }
+    };
+    auto list_emit = [&](uint32_t c) {
+        const uint32_t base = (uint32_t)__shfl((int)wl_base, wl_cls < 0 ? 0 : wl_cls, 64);      // (lane k holds class k's base)
+        if (wl_cls >= 0) {
+            uint32_t* list = work_list(work, false, wl_cls, max_chunks);
+            if (wl_halves) { list[base + wl_below] = c | kItemBack; list[base + wl_below + 1u] = c | kItemFront; }
+            else list[base + wl_below] = c;
+        }
+    };
+
+    for (uint32_t sb = c0; sb < c1; sb += kParBatch) {
+        sb_last = sb;
+        const uint32_t g0 = sb + (uint32_t)grp * U;
+        uint32_t meta_l = 0u;                 // lane u: chunk g0 + u's flag word
+        float l5[DEPTH ? U : 1];
+        if (g0 < c1) {
+            if (lane < (uint32_t)U) meta_l = chunk_meta[min(g0 + lane, c1 - 1u)];
+            if (DEPTH) {
+#pragma unroll
+                for (int u = 0; u < U; u++) l5[u] = *state_ptr(chunk_state, min(g0 + u, c1 - 1u), 5, pix);
+            }
+        }
+        load_states(g0);
+        publish(g0, l5);
+        nonmono = nonmono || __builtin_amdgcn_ballot_w64((meta_l & kMetaNonMono) != 0u) != 0ull;
+        __syncthreads();
+        // what stands in front of this group (pm, pe); the state behind the whole batch
+        float pm = 1.f; int pe = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g == grp) { pm = m; pe = e; }
+            const float Tv = ldexpf(m, e);
+            C0 += Tv * s_agg[g][0][pix]; C1 += Tv * s_agg[g][1][pix]; C2 += Tv * s_agg[g][2][pix];
+            if (DEPTH) Dm += Tv * s_agg[g][3][pix];
+            m *= s_agg[g][NA - 2][pix];
+            e += __float_as_int(s_agg[g][NA - 1][pix]);
+            renorm(m, e);
+        }
+        if (need_bwd && g0 < c1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = g0 + u;
+                if (c < c1) {
+                    // occlusion cut (see the kernel above): quadrant `quad` of chunk c is dark when every pixel enters with
+                    // |T| < 2^-(cut + growth bits of c)
+                    const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)meta_l, u) >> GSX_META_GROWTH_SHIFT;
+                    const bool darkp = gb < GSX_META_GROWTH_MAX && !tiny && (!inside || pm == 0.0f || pe <= -cut - (int)gb);
+                    const bool all_dark = __builtin_amdgcn_ballot_w64(!darkp) == 0ull;
+                    if (lane == 0u) {
+                        reinterpret_cast<uint8_t*>(chunk_dark + c)[quad] = all_dark ? 1 : 0;
+                        s_dark[grp * U + u][quad] = all_dark ? 1 : 0;
+                    }
+                    pm *= l3[u];
+                    pe += __float_as_int(l4[u]);
+                    renorm(pm, pe);
+                    *state_ptr(chunk_state, c, 6, pix) = pm; *state_ptr(chunk_state, c, 7, pix) = __int_as_float(pe);
+                }
+            }
+        }
+        __syncthreads();                      // s_dark is complete; s_agg may be rewritten
+        if (need_bwd && threadIdx.x < 64u) {
+            // Work lists of the backward by expected cost (see the kernel above), lane = chunk: one reservation per class per batch
+            const uint32_t c = sb + lane;
+            int cls = -1; bool halves = false;
+            if (c < c1 && lane < (uint32_t)kParBatch) {
+                const uint32_t meta = chunk_meta[c];
+                const uint32_t n_dark = (uint32_t)(s_dark[lane][0] + s_dark[lane][1] + s_dark[lane][2] + s_dark[lane][3]);
+                uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);
+                if (ch >= 128u && n_dark != 4u) {
+                    const uint32_t len = (c + 1u < c1) ? ch : (ranges[2 * tile + 1] - ranges[2 * tile]) - (c - c0) * ch;
+                    halves = len > (ch >> 1);
+                }
+                if (halves) { est >>= 1; cls = est >= 5u * ch ? 0 : est >= 3u * ch ? 1 : est >= 3u * (ch >> 1) ? 2 : 3; }
+                else cls = n_dark == 4u ? 4 : est >= 10u * ch ? 0 : est >= 6u * ch ? 1 : est >= 3u * ch ? 2 : 3;
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long hv = __builtin_amdgcn_ballot_w64(halves);
+            uint32_t mine = 0u, below = 0u;
+#pragma unroll
+            for (int k = 0; k < kWorkClasses; k++) {
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == k);
+                if ((int)lane == k) mine = (uint32_t)(__popcll(mk) + __popcll(mk & hv));
+                if (cls == k) below = (uint32_t)(__popcll(mk & lt) + __popcll(mk & hv & lt));
+            }
+            uint32_t base = 0u;
+            if (lane < (uint32_t)kWorkClasses && mine) base = atomicAdd(work_counters(work, false) + lane, mine);
+            wl_cls = cls; wl_halves = halves; wl_base = base; wl_below = below;
+            if (sb + kParBatch < c1) list_emit(c);          // (the last batch's round trip runs under the backward scan)
+        }
+    }
+    const float A = 1.0f - ldexpf(m, e);
+    if (grp == 0 && inside) {
+        const size_t P = (size_t)H * W, p = (size_t)y * W + x;
+        rgb[p] = C0; rgb[P + p] = C1; rgb[2*P + p] = C2;
+        alpha[p] = A;
+        if (DEPTH) depth_map[p] = Dm;
+    }
+    {
+        // the veto of the global early exit and the non-monotone flag: as in the kernel above
+        const bool tile_nonmono = __syncthreads_or(nonmono) != 0;
+        const bool unsat = grp == 0 && inside && (A <= GSX_SAT_ALPHA - 1e-5f) && !tile_nonmono;
+        const uint32_t raise = (__syncthreads_or(unsat) ? 1u : 0u) | (tile_nonmono ? 2u : 0u);
+        if (raise && threadIdx.x == 0 &&
+            (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & raise) != raise) atomicOr(state + 1, raise);
+    }
+    if (need_bwd && c1 > c0) {
+        // the last batch: states still in registers, the groups' results still in LDS
+        float F0 = 0.f, F1 = 0.f, F2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        behind(F0, F1, F2, b0, b1, b2);
+        scan_back(sb_last + (uint32_t)grp * U, b0, b1, b2);
+        if (threadIdx.x < 64u) list_emit(sb_last + lane);
+        for (uint32_t sb = sb_last; sb > c0; ) {                 // earlier batches: full, reloaded
+            sb -= kParBatch;
+            const uint32_t g0 = sb + (uint32_t)grp * U;
+            load_states(g0);
+            __syncthreads();                                     // everybody has read the previous batch's results
+            publish(g0, nullptr);
+            __syncthreads();
+            behind(F0, F1, F2, b0, b1, b2);
+            scan_back(g0, b0, b1, b2);
+        }
+    }
+    __syncthreads();                          // the next tile rewrites s_agg and s_dark
     }
 }
 
@@ -1340,6 +1624,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* hdr = meta + tail_hdr_offset((size_t)max_chunks);                             // published headers, level-order table, payloads
     uint32_t* order_tab = hdr + max_chunks;
     uint32_t* pay = order_tab + max_chunks;
+    // shallow views' combine pass: one workgroup per non-empty tile up to kParGrid of them, then a stride
+    const dim3 gp((unsigned)std::min<int64_t>(std::min<int64_t>(n_tiles, max_chunks > 0 ? max_chunks : 1), kParGrid));
     if (max_chunks <= 0) clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // otherwise block 0 of the chunk pass clears them
     else if (could_be_deep) {                               // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
         // the level-order table (its kernel also clears the payloads and the tiles' words), then the header pass: four
@@ -1360,12 +1646,14 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     if (depth_map) {
         if (max_chunks > 0) chunk_fwd_wg_kernel<true><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, true, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
+        tile_list_kernel<<<dim3((unsigned)((n_tiles + kListTiles - 1) / kListTiles)), dim3(kBlock), 0, st>>>(chunk_base, H, W, tw, n_tiles, state, work, order_tab, rgb, alpha, depth_map);
+        tile_combine_par_kernel<true><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
         if (max_chunks > 0) chunk_fwd_wg_kernel<false><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_combine_kernel<false, false, false><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 1);
+        tile_list_kernel<<<dim3((unsigned)((n_tiles + kListTiles - 1) / kListTiles)), dim3(kBlock), 0, st>>>(chunk_base, H, W, tw, n_tiles, state, work, order_tab, rgb, alpha, depth_map);
+        tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
