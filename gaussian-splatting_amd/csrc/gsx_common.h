@@ -76,4 +76,16 @@ __device__ __forceinline__ void wave_match_rank(uint32_t d, bool valid, uint32_t
     count = __popc(plo) + __popc(phi);
 }
 
+// ---- inside the library only (the one-call trainer step, gsx_view.hip): the image loss with its final reduction left to
+// the step's last kernel -- the loss value is a report, nothing on the GPU waits for it, and a launch of its own for one
+// workgroup costs as much of the stream as a thousand (4.6 us of a 0.77 ms step)
+constexpr int kLossBlocks = 1024;      // partial sums of the image losses (one per workgroup, fixed slices: deterministic)
+int image_loss_fwd_grad_partials(int32_t kind, const float* pred, const float* target, int64_t n, float* d_pred_unit,
+                                 void* ws, size_t ws_bytes, void* stream);
+int preprocess_bwd_with_loss(const float* positions, const float* scales, const float* rotations,
+                             const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
+                             const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
+                             int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
+                             float* g_features, const double* loss_partials, int64_t loss_n, float* loss, void* stream);
+
 }  // namespace gsx

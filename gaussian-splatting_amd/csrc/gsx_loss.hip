@@ -10,7 +10,6 @@
 
 namespace gsx {
 
-constexpr int kLossBlocks = 1024;
 constexpr float kClampLo = 1e-8f, kClampHi = 1.0f - 1e-8f;     // the reference's fp32 constants (1 - 1e-8 == 1.0f)
 
 template <int KIND>
@@ -439,6 +438,27 @@ GSX_API int gsx_image_loss_fwd_grad(int32_t kind, const float* pred, const float
         else loss_partial_grad_kernel<GSX_LOSS_CLAMPED_MSE, false><<<grid, block, 0, st>>>(pred, target, n, partials, d_pred_unit);
     }
     loss_final_kernel<<<dim3(1), dim3(kBlock), 0, st>>>(partials, n, loss);
+    GSX_LAUNCH_CHECK();
+    return GSX_OK;
+}
+
+// the two launches above without the second: the caller's last kernel reduces the partial sums (gsx_common.h)
+int gsx::image_loss_fwd_grad_partials(int32_t kind, const float* pred, const float* target, int64_t n, float* d_pred_unit,
+                                      void* ws, size_t ws_bytes, void* stream)
+{
+    if ((kind != GSX_LOSS_L1 && kind != GSX_LOSS_CLAMPED_MSE) || n <= 0 || !pred || !target || !d_pred_unit) return GSX_E_INVALID;
+    if (!ws || ws_bytes < gsx_image_loss_workspace_bytes()) return GSX_E_INVALID;
+    const bool vec = (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)d_pred_unit) & 15u) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    double* partials = (double*)ws;
+    const dim3 grid(kLossBlocks), block(kBlock);
+    if (kind == GSX_LOSS_L1) {
+        if (vec) loss_partial_grad_kernel<GSX_LOSS_L1, true><<<grid, block, 0, st>>>(pred, target, n, partials, d_pred_unit);
+        else loss_partial_grad_kernel<GSX_LOSS_L1, false><<<grid, block, 0, st>>>(pred, target, n, partials, d_pred_unit);
+    } else {
+        if (vec) loss_partial_grad_kernel<GSX_LOSS_CLAMPED_MSE, true><<<grid, block, 0, st>>>(pred, target, n, partials, d_pred_unit);
+        else loss_partial_grad_kernel<GSX_LOSS_CLAMPED_MSE, false><<<grid, block, 0, st>>>(pred, target, n, partials, d_pred_unit);
+    }
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -201,8 +201,20 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float* __restrict__ partials, const uint32_t* __restrict__ state,
     const float* __restrict__ d_mean2d, const float* __restrict__ d_depth, const float* __restrict__ d_cov2d,
     int N, int accumulate,
-    float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea)
+    float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea,
+    const double* __restrict__ loss_partials, long long loss_n, float* __restrict__ loss)
 {
+    if (loss && blockIdx.x == gridDim.x - 1) {
+        // the one-call trainer step's loss value: gsx_loss.hip's loss_final_kernel, same order of summation (same bits), by
+        // the last workgroup of the step's last backward kernel instead of a launch of its own
+        __shared__ double s_v[kBlock];
+        double s = 0.0;
+        for (int i = threadIdx.x; i < kLossBlocks; i += kBlock) s += loss_partials[i];
+        s_v[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = kBlock / 2; d > 0; d >>= 1) { if (threadIdx.x < d) s_v[threadIdx.x] += s_v[threadIdx.x + d]; __syncthreads(); }
+        if (threadIdx.x == 0) loss[0] = (float)(s_v[0] / (double)loss_n);
+    }
     const int g = blockIdx.x * kBlock + threadIdx.x;        // N is rounded up to whole waves below: no early return before the shuffles
     const int lane = threadIdx.x & 63;
     const bool live = g < N;
@@ -399,7 +411,27 @@ GSX_API int gsx_preprocess_bwd(const float* positions, const float* scales, cons
     if (d_cov2d && ((uintptr_t)d_cov2d & 15u)) return GSX_E_INVALID;
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
-        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features);
+        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features, nullptr, 0, nullptr);
+    GSX_LAUNCH_CHECK();
+    return GSX_OK;
+}
+
+// the same for the one-call trainer step (no upstream gradients besides the image's, no accumulation), with the image
+// loss's final reduction riding on the last workgroup (gsx_common.h)
+int gsx::preprocess_bwd_with_loss(const float* positions, const float* scales, const float* rotations,
+                                  const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
+                                  const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
+                                  int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
+                                  float* g_features, const double* loss_partials, int64_t loss_n, float* loss, void* stream)
+{
+    if (N <= 0) return GSX_E_INVALID;
+    if (!positions || !scales || !rotations || !pose || !rank_of || !offsets || !tiles_touched || !partials) return GSX_E_INVALID;
+    if (!g_positions || !g_scales || !g_rotations || !g_opacity || !g_features) return GSX_E_INVALID;
+    if (((uintptr_t)rotations | (uintptr_t)g_rotations) & 15u) return GSX_E_INVALID;
+    if (loss && (!loss_partials || loss_n <= 0)) return GSX_E_INVALID;
+    preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+        positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
+        nullptr, nullptr, nullptr, N, 0, g_positions, g_scales, g_rotations, g_opacity, g_features, loss_partials, (long long)loss_n, loss);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -176,7 +176,8 @@ GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream)
         if (st != GSX_OK) return st;
         st = gsx_l1_ssim_bwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, nullptr, s->loss_ws, s->loss_ws_bytes, s->d_rgb, stream);
     } else {
-        st = gsx_image_loss_fwd_grad(s->loss_kind, s->rgb, s->target, px, s->loss, s->d_rgb, s->loss_ws, s->loss_ws_bytes, stream);
+        // (the loss VALUE is reduced by the last kernel of this half: preprocess_bwd_with_loss)
+        st = gsx::image_loss_fwd_grad_partials(s->loss_kind, s->rgb, s->target, px, s->d_rgb, s->loss_ws, s->loss_ws_bytes, stream);
     }
     if (st != GSX_OK) return st;
     // The verdict on this step's optimism, BEFORE the backward is enqueued: a forward whose buffers were too small is
@@ -195,10 +196,11 @@ GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream)
                            s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,
                            s->d_rgb, partials, D, stream);
     if (st != GSX_OK) return st;
-    st = gsx_preprocess_bwd(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
-                            u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, nullptr, nullptr, nullptr, s->N, 0,
-                            s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4], stream);
-    return st;
+    const bool fold_loss = s->loss_kind != GSX_LOSS_L1_SSIM;
+    return gsx::preprocess_bwd_with_loss(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
+                                    u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, s->N,
+                                    s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4],
+                                    fold_loss ? static_cast<const double*>(s->loss_ws) : nullptr, px, fold_loss ? s->loss : nullptr, stream);
 }
 
 GSX_API int gsx_train_step_apply(const gsx_step* s, void* stream)
