@@ -27,7 +27,7 @@ SYMBOLS = [
 ABI_VERSION = 20            # GSX_ABI_VERSION of include/gsx.h (tests check that the two agree)
 GSX_OK, GSX_E_INVALID, GSX_E_CAPACITY, GSX_E_HIP, GSX_E_RANGE, GSX_E_AGAIN, GSX_E_COMM = 0, -1, -2, -3, -4, -5, -6
 RANK_NONE = 0xFFFFFFFF
-REC_FLOATS = 12
+REC_FLOATS = int(os.environ.get("GSX_REC_FLOATS", "12"))      # (16 only with a library built for the 64-byte-stride experiment)
 TILE = 16
 CHUNK = 256
 STATE_WORDS = 8

@@ -23,6 +23,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 constexpr int kBlock = 256;        // 4 wave64
+constexpr int kRecVec = GSX_REC_FLOATS / 4;      // float4s per rank-ordered record (its stride; the first three hold the record)
 constexpr int kWave = 64;
 
 // Instances per compositing chunk for a view of D instances (gsx_constants.h): one wave composites one chunk, so a small

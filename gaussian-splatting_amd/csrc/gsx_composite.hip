@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void grower_bitmap_kernel(const float4* __r
     if (min(chunk_base[n_tiles], max_chunks) < kDeepChunks) return;
     const uint32_t r = blockIdx.x * kBlock + threadIdx.x;      // N is rounded up to whole waves: every lane reaches the ballot
     bool grower = false;
-    if (r < N) { const float4* R = rec + (size_t)3 * r; grower = growth_term(R[0], R[1]) != 0.0f; }      // NaN counts
+    if (r < N) { const float4* R = rec + (size_t)kRecVec * r; grower = growth_term(R[0], R[1]) != 0.0f; }      // NaN counts
     const unsigned long long m = __builtin_amdgcn_ballot_w64(grower);
     if ((threadIdx.x & 63) == 0 && r < N) {                    // (a wave wholly past the end has no words: the count sits there)
         bitmap[(r >> 5)] = (uint32_t)m; bitmap[(r >> 5) + 1] = (uint32_t)(m >> 32);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void tile_growth_kernel(const float4* __res
         for (uint32_t i = g.begin + lane; i < g.end; i += kCBatch) {
             const uint32_t r = ranks[i];
             if (!bitmap || ((bitmap[r >> 5] >> (r & 31u)) & 1u)) {
-                const float4* R = rec + (size_t)3 * r;
+                const float4* R = rec + (size_t)kRecVec * r;
                 pre += growth_term(R[0], R[1]);
                 any = true;
             }
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
         bool past_exit = false;
         if (i < g.end) {
             const uint32_t r = ranks[i];
-            const float4* R = rec + (size_t)3 * r;
+            const float4* R = rec + (size_t)kRecVec * r;
             const float4 a = R[0], b = R[1];
             const float gt = growth_term(a, b);
             growth += gt;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
         uint32_t my_mask = 0u;
         if (i < my_end) {
             const uint32_t r = ranks[i];
-            const float4* R = rec + (size_t)3 * r;
+            const float4* R = rec + (size_t)kRecVec * r;
             const float4 a = R[0], b = R[1];
             const float gt = growth_term(a, b);
             growth = gt;
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 if (i < end) {
                     const uint32_t r = ranks[i];
                     s_rank[threadIdx.x] = r;
-                    const float4* R = rec + (size_t)3 * r;
+                    const float4* R = rec + (size_t)kRecVec * r;
                     s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1];
                 }
                 __syncthreads();
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         uint32_t my_mask = 0u;
         if ((uint32_t)lane < cnt) {
             const uint32_t r = ranks[bs + lane];
-            const float4* R = rec + (size_t)3 * r;
+            const float4* R = rec + (size_t)kRecVec * r;
             float4 c = R[2];
             const uint32_t bx = __float_as_uint(c.z), by = __float_as_uint(c.w);
             const int tx0 = (int)(bx & 0xffff) >> GSX_TILE_SHIFT, tx1 = ((int)(bx >> 16) >> GSX_TILE_SHIFT) + 1;

@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ 
     if (tile_box) tile_box[r] = tt ? ((uint32_t)(xlo >> GSX_TILE_SHIFT) | ((uint32_t)(ylo >> GSX_TILE_SHIFT) << 8) |
                                       ((uint32_t)(xhi >> GSX_TILE_SHIFT) << 16) | ((uint32_t)(yhi >> GSX_TILE_SHIFT) << 24)) : 0x00000001u;
     const uint32_t bx = (uint32_t)xlo | ((uint32_t)xhi << 16), by = (uint32_t)ylo | ((uint32_t)yhi << 16);
-    float4* R = reinterpret_cast<float4*>(rec) + (size_t)3 * r;
+    float4* R = reinterpret_cast<float4*>(rec) + (size_t)kRecVec * r;
     R[0] = make_float4(mu.x, mu.y, m[0] * GSX_NEG_HALF_LOG2E, (m[1] + m[2]) * GSX_NEG_HALF_LOG2E);
     R[1] = make_float4(m[3] * GSX_NEG_HALF_LOG2E, op, p2.x, p2.y);
     R[2] = make_float4(p2.z, p1.z, __uint_as_float(bx), __uint_as_float(by));

@@ -55,7 +55,9 @@
  * box_x / box_y are the bit patterns of (xlo | xhi<<16) and (ylo | yhi<<16): the footprint's pixel
  * bounding box, inclusive, clamped to the image; lo > hi (1,0) marks an empty footprint.  The tile
  * rectangle is [lo >> 4, (hi >> 4) + 1).  Images are limited to 65535 pixels per side. */
+#ifndef GSX_REC_FLOATS          /* (overridable for the 64-byte-stride experiment of DESIGN.md section 4 only: 16 = one record per 64-byte sector) */
 #define GSX_REC_FLOATS 12
+#endif
 
 /* compositing work item: at most GSX_CHUNK consecutive instances of one tile's depth-ordered list,
  * composited by one wave64 (4 pixels per lane); chunk results are combined per tile afterwards
