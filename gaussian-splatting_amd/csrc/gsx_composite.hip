@@ -1369,54 +1369,41 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
 // ------------------------------------------------------------------------------------------
 // B1: backward, one wave per chunk, back to front
 // ------------------------------------------------------------------------------------------
-// Reduce the NINE per-lane sums of one splat over the wave in one hand-scheduled block.
-//   a0..a7: reduce-scatter -- v_permlane32_swap / v_permlane16_swap halve the register count at distances 32
-//           and 16, a DPP rotate + select at distance 8, three DPP adds inside each 8-lane group; lane l ends
-//           up with the wave total of value (l >> 3).
-//   b     : plain DPP reduction (4 row steps, row_bcast:15, row_bcast:31), total valid in lane 63.
-// Returned: lane 63 -> total of b, every other lane l -> total of a[l >> 3].  Fixed order -> deterministic.
-// Why asm: (1) ROCm 7.2's __builtin_amdgcn_permlane{32,16}_swap returns the FIRST register for both results;
-// (2) a DPP or permlane-swap read needs 2 wait states after the VALU write of its source, and an s_nop costs
-// a full 4-cycle issue slot on gfx950 -- written as separate statements this reduction carried 18 of them
-// (a third of its issue time).  Here the two dependency chains are interleaved so that 4 remain.
-// Slot numbers in the comments: producer -> consumer distances are all >= 3 (2 instructions between).
-__device__ __forceinline__ float wave_reduce9(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
-                                              float b, unsigned long long hi8_mask, unsigned long long lane63_mask)
+// The nine per-lane sums of one splat reach their row through LDS (round 3, second half): every lane parks its nine values in a
+// staging slot -- nine `ds_write_addtid_b32` (address = M0 + offset + 4 * lane: no address register, 2 cycles each), row v of the slot
+// = value v of all 64 lanes -- and after kRedK splats lane t < 2 * 9 * kRedK adds up HALF a row (8 ds_read_b128, 31 adds), one DPP add
+// joins the halves, and lane (slot j, value v) stores its total straight into the instance's row.  ~15 VALU instructions per splat at
+// the plain-add rate instead of the 25 cross-lane ones of `wave_reduce9` (permlane swaps and DPP adds issue at a third to a half of that
+// rate: profiles/r3_valu_issue_rate.txt), and no output staging.  Rows are 64 + 4 floats apart so that the 16 lanes of a ds_read_b128
+// group (two halves of eight consecutive rows) hit 16 different bank quads.  Fixed order of summation: bitwise reproducible.
+#ifndef GSX_RED_K
+#define GSX_RED_K 2
+#endif
+constexpr int kRedK = GSX_RED_K;               // splats per flush (2: 36 of the 64 lanes sum, 7.3 KB of LDS per wave; 3: 54 lanes, 9.7 KB -- fewer
+                                               // instructions and one resident wave per SIMD less: 0.744 against 0.735 ms per bench step)
+constexpr int kRedRow = 68;                    // floats from one row of a slot to the next
+constexpr int kRedSlot = 9 * kRedRow;          // floats per slot
+
+// row order of a slot = order of the instance's row in `partials`: S(dq dx), S(dq dy), S(dq dx dx), S(dq dx dy), S(dq dy dy), S(dq), S(w G0..2)
+__device__ __forceinline__ void stage_sums(uint32_t lds_byte_base, float r0, float r1, float r2, float r3, float r4, float r5,
+                                           float r6, float r7, float r8)
 {
     asm volatile(
-        "s_nop 1\n\t"                                                                     //  0 inputs may be fresh
-        "v_permlane32_swap_b32 %0, %4\n\t"                                                //  1
-        "v_permlane32_swap_b32 %2, %6\n\t"                                                //  2
-        "v_permlane32_swap_b32 %1, %5\n\t"                                                //  3
-        "v_permlane32_swap_b32 %3, %7\n\t"                                                //  4
-        "v_add_f32 %0, %0, %4\n\t"                                                        //  5 u0 (1)
-        "v_add_f32 %2, %2, %6\n\t"                                                        //  6 u2 (2)
-        "v_add_f32 %1, %1, %5\n\t"                                                        //  7 u1 (3)
-        "v_add_f32 %3, %3, %7\n\t"                                                        //  8 u3 (4)
-        "v_permlane16_swap_b32 %0, %2\n\t"                                                //  9 (5, 6)
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // 10 b
-        "v_permlane16_swap_b32 %1, %3\n\t"                                                // 11 (7, 8)
-        "v_add_f32 %0, %0, %2\n\t"                                                        // 12 w0 (9)
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // 13 b (10)
-        "v_add_f32 %1, %1, %3\n\t"                                                        // 14 w1 (11)
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"               // 15 (12)
-        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         // 16 b (13)
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"               // 17 (14)
-        "v_cndmask_b32_e64 %0, %0, %1, %9\n\t"                                            // 18 z = lane&8 ? w1' : w0'
-        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"              // 19 b (16)
-        "s_nop 0\n\t"                                                                     // 20
-        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         // 21 z (18)
-        "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"            // 22 b (19): rows 1,3 += row 0,2 totals
-        "s_nop 0\n\t"                                                                     // 23
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // 24 z (21)
-        "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"            // 25 b (22): rows 2,3 += lane 31
-        "s_nop 0\n\t"                                                                     // 26
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // 27 z (24)
-        "v_cndmask_b32_e64 %0, %0, %8, %10"                                                 // 28 lane 63 takes b
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b)
-        : "s"(hi8_mask), "s"(lane63_mask));
-    return a0;
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"                                  // SALU write of M0 -> LDS add-TID instruction: one wait state
+        "ds_write_addtid_b32 %0 offset:0\n\t"
+        "ds_write_addtid_b32 %1 offset:272\n\t"
+        "ds_write_addtid_b32 %2 offset:544\n\t"
+        "ds_write_addtid_b32 %3 offset:816\n\t"
+        "ds_write_addtid_b32 %4 offset:1088\n\t"
+        "ds_write_addtid_b32 %5 offset:1360\n\t"
+        "ds_write_addtid_b32 %6 offset:1632\n\t"
+        "ds_write_addtid_b32 %7 offset:1904\n\t"
+        "ds_write_addtid_b32 %8 offset:2176"
+        :: "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(r8), "s"(lds_byte_base)
+        : "memory");
 }
+static_assert(kRedRow * 4 == 272, "the offsets in stage_sums are rows of kRedRow floats");
 
 __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
@@ -1426,17 +1413,19 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed,
     uint32_t max_chunks, const float* __restrict__ mid_state)
 {
-    __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
+    __shared__ float4 s_a[kCBatch], s_b[kCBatch];
+    __shared__ float s_cx[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
-    // raw sums per staged splat: dq, dq*dx, dq*dy, dq*dx*dx, dq*dx*dy, dq*dy*dy (dq = dL/dalpha * alpha), w*G0..2;
-    // the second half is a dump area for the lanes that hold no sum (one bank each)
-    __shared__ float s_red[2 * kCBatch * 9 + 64];
-    // work lists left by the combine pass (gridDim.x == max_chunks), costliest class first, occluded chunks last;
+    // staging slots of the row sums (above)
+    __shared__ __align__(16) float s_stage[kRedK * kRedSlot];
+    // work lists left by the combine pass, costliest class first, occluded chunks last;
     // the second set is the one rebuilt after a global early exit
     const uint32_t limit = rank_limit_from_state(state, N);
     const bool after_exit = limit < N;
     const uint32_t* cnt = work_counters(const_cast<uint32_t*>(work), after_exit);
-    uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    // one work item (a chunk, or half a chunk of a shallow view)
+    auto bwd_item = [&](uint32_t b) {
     int cls = 0;
     while (cls < kWorkClasses && b >= cnt[cls]) { b -= cnt[cls]; cls++; }       // costliest class first
     if (cls == kWorkClasses) return;
@@ -1457,7 +1446,6 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         eff_end = lo;
     }
     if (eff_end == g.begin) return;
-    const int lane = threadIdx.x;
     // Occlusion cut (the transmittance twin of the footprint cut): if every pixel of a quadrant enters this chunk
     // with |T| < 2^-(GSX_CUT_LOG2 + g), g = the chunk's bound on the growth of |T| in bits (0 unless an opacity lies outside [0, 2]),
     // every weight T*alpha there is below 2^-24 and so is every dL/dalpha per unit of upstream gradient: the
@@ -1489,8 +1477,13 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const int qx = g.tx * GSX_TILE, qy = g.ty * GSX_TILE;
     const QuadEdges QE = quad_edges(qx, qy, H, W, stepx, stepy);
     const size_t P = (size_t)H * W;
-    const uint32_t out_lane = (lane == 63) ? 8u : ((lane & 7) == 0) ? (uint32_t)(lane >> 3) : (uint32_t)(kCBatch * 9 + lane);
-    const unsigned long long hi8_mask = 0xFF00FF00FF00FF00ull, lane63_mask = 0x8000000000000000ull;
+    // the summing lanes of a flush: lane t adds up half `t & 1` of row `t >> 1` (= slot tj, value tv)
+    const int t_row = min(lane >> 1, 9 * kRedK - 1);
+    const int tj = t_row / 9, tv = t_row - tj * 9;
+    const float* t_src = s_stage + t_row * kRedRow + (lane & 1) * 32;
+    const bool t_store = (lane & 1) == 0 && lane < 2 * 9 * kRedK;
+    const float t_fac = (tv >= 2 && tv <= 4) ? GSX_LN2 : 1.0f;
+    const uint32_t stage_base = (uint32_t)(uintptr_t)s_stage;          // byte offset of the staging area in the LDS
     float G0[4], G1[4], G2[4], Wb[4], m[4]; int e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1513,6 +1506,22 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         }
         Wb[k] = G0[k] * b0 + G1[k] * b1 + G2[k] * b2;
     }
+    // one flush: the staged splats j0, j1, j2 (the first `n` of them) get their rows
+    auto flush = [&](uint32_t n, uint32_t j0, uint32_t j1, uint32_t j2) {
+        const float4* src = reinterpret_cast<const float4*>(t_src);
+        const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3], r4 = src[4], r5 = src[5], r6 = src[6], r7 = src[7];
+        const uint32_t js = tj == 0 ? j0 : tj == 1 ? j1 : j2;
+        const uint32_t slot = s_slot[js];
+        const float opa = s_b[js].y;
+        float acc = (((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w)))
+                  + (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
+        acc += (((r4.x + r4.y) + (r4.z + r4.w)) + ((r5.x + r5.y) + (r5.z + r5.w)))
+             + (((r6.x + r6.y) + (r6.z + r6.w)) + ((r7.x + r7.y) + (r7.z + r7.w)));
+        // the other half of the row sits in the neighbouring lane
+        acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+        const float out = acc * ((tv == 5) ? __builtin_amdgcn_rcpf(opa) : t_fac);          // d opacity = S(dq) / o
+        if (t_store && (uint32_t)tj < n) partials[(size_t)slot * 9u + (uint32_t)tv] = out;
+    };
     const uint32_t nb = (eff_end - g.begin + kCBatch - 1) / kCBatch;
     uint32_t active = 0;
     for (uint32_t bi = nb; bi-- > 0; ) {
@@ -1529,7 +1538,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
             const float4 a = R[0], b = R[1];
             my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE) & ~dark_mask;
-            s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
+            s_a[lane] = a; s_b[lane] = b; s_cx[lane] = c.x;
         }
         // The batch's quadrant masks as four wave-uniform bit sets (bit j of qk: instance j reaches quadrant k, dark quadrants
         // taken out): they live in scalar registers, so the loop below neither reads a mask from LDS nor waits for it before
@@ -1539,11 +1548,11 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
         const unsigned long long q2 = __builtin_amdgcn_ballot_w64((my_mask & 4u) != 0u), q3 = __builtin_amdgcn_ballot_w64((my_mask & 8u) != 0u);
         const unsigned long long live = (q0 | q1) | (q2 | q3);
         __syncthreads();
+        uint32_t nst = 0, j0 = 0, j1 = 0, j2 = 0;                       // staged splats of the current flush (wave-uniform)
         for (unsigned long long todo = live; todo != 0ull; ) {
             const uint32_t j = 63u - (uint32_t)__builtin_clzll(todo);       // back to front
             todo &= ~(1ull << j);
-            const uint32_t slot = (out_lane + j * 9u) * 4u;       // byte offset into s_red
-            const float4 a = s_a[j], b = s_b[j], c = s_c[j];
+            const float4 a = s_a[j], b = s_b[j]; const float cx = s_cx[j];
             const unsigned long long bit = 1ull << j;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
 #pragma unroll
@@ -1555,11 +1564,13 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
                     const float f = one_minus(al);
                     m[k] *= __builtin_amdgcn_rcpf(f);                 // T_k = T_{k+1} / (1 - alpha_k)
                     const float Tv = ldexpf(m[k], e[k]);
-                    const float cG = b.z * G0[k] + b.w * G1[k] + c.x * G2[k];
-                    const float dal = Tv * (cG - Wb[k]);              // dL/dalpha_k
-                    Wb[k] = al * cG + f * Wb[k];
-                    const float dq = dal * al;                        // dL/dq' / ln2  (alpha = o * exp2(q'))
+                    const float cG = b.z * G0[k] + b.w * G1[k] + cx * G2[k];
+                    const float diff = cG - Wb[k];                    // dL/dalpha_k = T_k (c_k.G - W_k)
                     const float wv = Tv * al;
+                    const float dq = wv * diff;                       // dL/dq' / ln2 = alpha_k dL/dalpha_k  (alpha = o * exp2(q'))
+                    // (not fma(al, diff, Wb): one instruction less, but where an opaque splat stands in front of something
+                    // bright the sum Wb + (cG - Wb) cancels -- fixture exit8's worst element went from 6e-4 to 3.4e-3 of the oracle)
+                    Wb[k] = al * cG + f * Wb[k];
                     s0 += dq; s1 += dq * dx; s2 += dq * dy;
                     s3 += dq * dx * dx; s4 += dq * dx * dy; s5 += dq * dy * dy;
                     s6 += wv * G0[k]; s7 += wv * G1[k]; s8 += wv * G2[k];
@@ -1569,26 +1580,23 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; k++) renorm(m[k], e[k]);
             }
-            // one unpredicated LDS store per splat: lanes 0,8,..,56 hold sums 0..7, lane 63 the ninth, every
-            // other lane writes into the dump area (two exec-masked stores cost 4x as much as this)
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(s_red) + slot) = wave_reduce9(s0, s1, s2, s3, s4, s5, s6, s7, s8, hi8_mask, lane63_mask);
+            stage_sums((uint32_t)__builtin_amdgcn_readfirstlane((int)(stage_base + nst * (uint32_t)(kRedSlot * 4))), s1, s2, s3, s4, s5, s0, s6, s7, s8);
+            if (nst == 0) j0 = j; else if (nst == 1) j1 = j; else j2 = j;
+            if (++nst == (uint32_t)kRedK) { flush(kRedK, j0, j1, j2); nst = 0; }
         }
-        __syncthreads();
-        // one row per instance: (dmu_x, dmu_y, dk00, dkb, dk11, d opacity, dr, dg, db)
-        for (uint32_t idx = lane; idx < cnt * 9u; idx += 64) {
-            const uint32_t j = idx / 9u, c = idx - j * 9u;
-            const float* sp = s_red + j * 9u;
-            float out;
-            if (!((live >> j) & 1ull)) out = 0.0f;                // never visited: nothing of it reaches a live quadrant
-            else if (c == 0) out = -GSX_LN2 * (2.0f * s_a[j].z * sp[1] + s_a[j].w * sp[2]);
-            else if (c == 1) out = -GSX_LN2 * (s_a[j].w * sp[1] + 2.0f * s_b[j].x * sp[2]);
-            else if (c <= 4) out = GSX_LN2 * sp[c + 1];
-            else if (c == 5) out = sp[0] / s_b[j].y;
-            else             out = sp[c];
-            partials[(size_t)s_slot[j] * 9u + c] = out;
+        if (nst) flush(nst, j0, j1, j2);
+        // instances the loop never visited (nothing of them reaches a live quadrant): zero rows
+        const unsigned long long unvisited = (cnt == 64u ? ~0ull : ((1ull << cnt) - 1ull)) & ~live;
+        if (unvisited != 0ull) {
+            for (uint32_t idx = lane; idx < cnt * 9u; idx += 64) {
+                const uint32_t j = idx / 9u, c = idx - j * 9u;
+                if ((unvisited >> j) & 1ull) partials[(size_t)s_slot[j] * 9u + c] = 0.0f;
+            }
         }
         __syncthreads();
     }
+    };
+    bwd_item(blockIdx.x);
 }
 
 }  // namespace gsx

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float4 qv = reinterpret_cast<const float4*>(rot)[g];
     const float q[4] = { qv.x, qv.y, qv.z, qv.w };
     Proj o; project_one(p, s, q, M, o);
-    // D: 0 dmu_x 1 dmu_y 2 dk00 3 dkb 4 dk11 5 d(opacity) 6..8 d(colour)
+    // D: 0 S(dq dx) 1 S(dq dy) (raw moments, chain rule below) 2 dk00 3 dkb 4 dk11 5 d(opacity) 6..8 d(colour)
     // conic -> covariance: dSigma = -M^T dM M^T, dM = c0 * [[D2, D3],[D3, D4]]
     const float a = o.cov[0] + GSX_COV_EPS, b = o.cov[1], c = o.cov[2], d = o.cov[3] + GSX_COV_EPS;
     float mi[4]; inv2x2(a, b, c, d, mi);
@@ -337,7 +337,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float dot = w*dw + x*dx + y*dy + z*dz;
     float gq[4] = { (dw - w*dot) / n, (dx - x*dot) / n, (dy - y*dot) / n, (dz - z*dot) / n };
     // mu = cam.xy / cam.z ; depth = cam.z
-    float dmx = D[0], dmy = D[1];
+    // rows 0, 1 of the backward's partial rows are the raw moments S(dq dx), S(dq dy); the conic is a per-splat constant, so
+    // the chain rule to the mean is taken once per Gaussian here, not once per (tile, splat) row there
+    float dmx = 0.0f, dmy = 0.0f;
+    if (tt > 0u) {
+        const float k00 = mi[0] * c0, kb = (mi[1] + mi[2]) * c0, k11 = mi[3] * c0;       // the record's conic (build_record_one)
+        dmx = -GSX_LN2 * (2.0f * k00 * D[0] + kb * D[1]);
+        dmy = -GSX_LN2 * (kb * D[0] + 2.0f * k11 * D[1]);
+    }
     if (d_mean2d) { const float2 u = reinterpret_cast<const float2*>(d_mean2d)[g]; dmx += u.x; dmy += u.y; }
     const float cz = o.cam[2];
     const float dcam[3] = { dmx / cz, dmy / cz, -(dmx * o.cam[0] + dmy * o.cam[1]) / (cz * cz) + (d_depth ? d_depth[g] : 0.0f) };

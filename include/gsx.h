@@ -212,10 +212,13 @@ int gsx_view_forward(const float* positions, const float* scales, const float* r
                      uint32_t* state /* 4 x u32, as gsx_composite_fwd */, int64_t* D_pinned_host, void* count_event, void* stream);
 
 /* ---- backward of compositing (the reference relies on autograd over :124-144).  One wave64 per
- * chunk walks it back to front from the chunk-end state the forward left, reduces the nine
- * per-splat partial sums over the wavefront (DPP) and stores ONE row per (tile, rank) instance at
+ * chunk walks it back to front from the chunk-end state the forward left, adds up the nine
+ * per-splat partial sums over the wavefront (through LDS: every lane parks its nine values, 2 x 9 x 2 lanes
+ * add up half a row each) and stores ONE row per (tile, rank) instance at
  * partials[offsets[rank] + tile index inside the splat's rectangle] -- no atomics; the
  * per-Gaussian sum happens in gsx_preprocess_bwd in a fixed order (bitwise reproducible).
+ * A row: S(dq dx), S(dq dy) (raw first moments about the splat's mean; dq = alpha dL/dalpha: gsx_preprocess_bwd takes the
+ * chain rule to the mean once per Gaussian), d k00, d kb, d k11 (the conic's entries), d opacity, d colour (3).
  * Occlusion cut: an 8x8 quadrant whose pixels all enter a chunk with |T| < 2^-(GSX_CUT_LOG2 + g), g = the chunk's
  * bound on the growth of |T| in bits (gsx_constants.h; 0 unless an opacity lies outside [0, 2]), is masked out for
  * that chunk: all its weights T*alpha stay below 2^-23, like the pairs the footprint cut drops.  A chunk with four
