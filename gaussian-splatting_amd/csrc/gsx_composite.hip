@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float w = ldexpf(m[k], e[k]) * al;
                     C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
@@ -642,7 +642,9 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
     float* __restrict__ mid_state)
 {
-    constexpr int kWords = 6;                 // C0 C1 C2 m e Dm
+    // C0 C1 C2 m e (Dm).  Without a depth map the parts are 20 KB instead of 24: seven workgroups per CU instead of six, i.e.
+    // seven waves per SIMD (65 VGPRs), and the chunk pass of the bench scene 195 -> 189 us with the combine pass
+    constexpr int kWords = DEPTH ? 6 : 5;
     // [wave][word][pixel of the tile]; the head of a wave's part doubles as its record staging (3 x 64 float4 = 3 KB of 6 KB),
     // which is dead when the wave parks its result there
     __shared__ float s_part[4][kWords][kPixPerTile];
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float w = ldexpf(m[k], e[k]) * al;
                     C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
@@ -1328,7 +1330,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                     const float4 a = s_a[j], b = s_b[j];
                     const float dx = gx - a.x, dy = gy - a.y;
-                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float am = b.y * __builtin_amdgcn_exp2f(q);
                     A = A + (1.0f - A) * am;
                     if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
@@ -1559,7 +1561,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float f = one_minus(al);
                     m[k] *= __builtin_amdgcn_rcpf(f);                 // T_k = T_{k+1} / (1 - alpha_k)
