@@ -176,12 +176,6 @@ __device__ __forceinline__ float* state_ptr(float* chunk_state, uint32_t chunk, 
     return chunk_state + ((size_t)chunk * GSX_STATE_WORDS + word) * kPixPerTile + pix;
 }
 
-__global__ void clear_state_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ work)
-{
-    if (threadIdx.x < 4) state[threadIdx.x] = 0u;
-    if (threadIdx.x < 16) work[threadIdx.x] = 0u;
-}
-
 // ------------------------------------------------------------------------------------------
 // Forward occlusion skipping.  The chunk pass composites all chunks of a tile in parallel, blind to the transmittance in
 // front of them; in a dense view a third to a half of the instances sit behind a wall of earlier splats (and in a
@@ -483,10 +477,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     uint32_t* __restrict__ hdr, uint32_t* __restrict__ pay, const uint32_t* __restrict__ order_tab, uint32_t* __restrict__ tile_dark)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch], s_c[kCBatch];
-    if (!PASS1 && blockIdx.x == 0) {          // the combine pass (next launch) counts in these; pass 0 itself reads neither
-        if (threadIdx.x < 4) state[threadIdx.x] = 0u;
-        if (threadIdx.x < 16) work[threadIdx.x] = 0u;
-    }
+    // (state[] and the work counters are cleared by block 0 of chunk_fwd_wg_kernel, which gsx_composite_fwd always launches in front)
     const uint32_t n_chunks = chunk_base[n_tiles];
     if (!PASS1 && DEEP != (n_chunks >= kDeepChunks)) return;          // the other instantiation's view
     uint32_t limit = N;
@@ -621,6 +612,55 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
     }
 }
 
+constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (written by the last list block of the chunk pass)
+constexpr int kListTiles = 16;            // tiles per list block
+
+// The tiles that hold something, as a list (order_tab's room: a shallow view has no level-order table), so that the combine pass
+// runs on those alone: the bench scene leaves 3600-3900 of its 4096 tiles empty, and a grid with one workgroup per
+// tile spent most of its time passing empty workgroups through the dispatcher in front of the 250-400 that have work.
+// The empty tiles' pixels are written here (zeros; alpha 0 is "not saturated": an empty tile vetoes the global exit).
+// Runs as the LAST blocks of the chunk pass's grid (a launch of its own until late in round 3: 6.4 us of launch floor), beside the
+// pass's tail.  No atomics: a block counts the non-empty tiles in front of its own from the chunk table (n_tiles words out of the
+// L2), so the list is in tile order and the same from run to run; the block that holds the last tile writes the count.
+__device__ __forceinline__ void tile_list_block(int lb, uint32_t* s_scratch /* >= 5 words */,
+    const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int n_tiles,
+    uint32_t* __restrict__ work, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
+{
+    const int t0 = lb * kListTiles;
+    uint32_t before = 0;
+    for (int t = (int)threadIdx.x; t < t0; t += kBlock) before += (chunk_base[t + 1] > chunk_base[t]) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_down((int)before, d, 64);
+    if ((threadIdx.x & 63u) == 0u) s_scratch[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const uint32_t base = (s_scratch[0] + s_scratch[1]) + (s_scratch[2] + s_scratch[3]);
+    if (threadIdx.x < 64u) {
+        const int t = t0 + (int)threadIdx.x;
+        const bool valid = threadIdx.x < (uint32_t)kListTiles && t < n_tiles;
+        const bool holds = valid && chunk_base[t + 1] > chunk_base[t];
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(holds), me = __builtin_amdgcn_ballot_w64(valid && !holds);
+        if (holds) list[base + (uint32_t)__popcll(mh & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)t;
+        if (threadIdx.x == 0u) {
+            s_scratch[4] = (uint32_t)me;
+            if (t0 + kListTiles >= n_tiles) work[kWorkNonEmpty] = base + (uint32_t)__popcll(mh);
+        }
+    }
+    __syncthreads();
+    uint32_t em = s_scratch[4];       // (the veto of the empty tiles: tile_combine_par_kernel, from the count)
+    const size_t P = (size_t)H * W;
+    while (em) {
+        const int tile = t0 + __builtin_ctz(em);
+        em &= em - 1u;
+        int x, y; pix_xy((int)(threadIdx.x >> 6), (int)(threadIdx.x & 63u), tile % tw, tile / tw, x, y);
+        if (x < W && y < H) {
+            const size_t p = (size_t)y * W + x;
+            rgb[p] = 0.f; rgb[P + p] = 0.f; rgb[2*P + p] = 0.f;
+            alpha[p] = 0.f;
+            if (depth_map) depth_map[p] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // F1w (round 3): the chunk pass of a SHALLOW view -- one WORKGROUP of four waves per chunk.  Wave w composites the chunk's
 // w-th quarter (at most 64 instances: one staged batch, no batch loop) from (C = 0, T = 1); the four partial results are
@@ -640,7 +680,8 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, int n_tiles, int H, int W, int tw, float stepx, float stepy,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
-    float* __restrict__ mid_state)
+    float* __restrict__ mid_state, uint32_t n_list_blocks, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha,
+    float* __restrict__ depth_map)
 {
     // C0 C1 C2 m e (Dm).  Without a depth map the parts are 20 KB instead of 24: seven workgroups per CU instead of six, i.e.
     // seven waves per SIMD (65 VGPRs), and the chunk pass of the bench scene 195 -> 189 us with the combine pass
@@ -652,10 +693,17 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     __shared__ float s_growth[4];
     if (blockIdx.x == 0) {                    // the combine pass (next launch) counts in these; the chunk pass itself reads neither
         if (threadIdx.x < 4) state[threadIdx.x] = 0u;
-        if (threadIdx.x < 16) work[threadIdx.x] = 0u;
+        if (threadIdx.x < 16 && threadIdx.x != (uint32_t)kWorkNonEmpty) work[threadIdx.x] = 0u;      // (work[5]: the last list block's)
     }
     const uint32_t n_chunks = chunk_base[n_tiles];
-    if (n_chunks >= kDeepChunks || blockIdx.x >= n_chunks) return;      // a deep view is the other kernel's (uniform over the workgroup)
+    if (n_chunks >= kDeepChunks) return;                                // a deep view is the other kernel's (uniform over the workgroup)
+    const uint32_t n_chunk_blocks = gridDim.x - n_list_blocks;
+    if (blockIdx.x >= n_chunk_blocks) {                                 // the grid's last blocks: list of non-empty tiles, empty tiles' pixels
+        tile_list_block((int)(blockIdx.x - n_chunk_blocks), reinterpret_cast<uint32_t*>(&s_part[0][0][0]), chunk_base, H, W, tw, n_tiles,
+                        work, list, rgb, alpha, depth_map);
+        return;
+    }
+    if (blockIdx.x >= n_chunks) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t chunk = chunk_of_block(blockIdx.x, n_chunks);
     const ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
@@ -779,7 +827,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
 // state[1] is raised if some pixel is clearly not saturated (the global early exit cannot fire).
 // ------------------------------------------------------------------------------------------
 // DEEP: as for the chunk pass.  Instantiated with it only since round 3: the deep views' pass 0 and every view's pass 1
-// (after a global early exit); a shallow view's pass 0 is tile_list_kernel + tile_combine_par_kernel below.
+// (after a global early exit); a shallow view's pass 0 is tile_combine_par_kernel below, on the list the chunk pass's last blocks leave.
 template <bool PASS1, bool DEPTH, bool DEEP>
 __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
     const uint32_t* __restrict__ chunk_base, uint32_t N, int H, int W, int tw, int need_bwd,
@@ -1005,49 +1053,6 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 constexpr int kParGroups = 4;
 template <bool DEPTH> struct ParShape { static constexpr int U = 12, Batch = kParGroups * U; };
 constexpr int kParGrid = 512;             // workgroups of the combine pass at most (one of 1024 threads fits a CU): beyond that, a stride
-constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (cleared with the counters by the chunk pass)
-constexpr int kListTiles = 16;            // tiles per workgroup of tile_list_kernel
-
-// The tiles that hold something, as a list (order_tab's room: a shallow view has no level-order table), so that the kernel
-// below runs on those alone: the bench scene leaves 3600-3900 of its 4096 tiles empty, and a grid with one workgroup per
-// tile spent most of its time passing empty workgroups through the dispatcher in front of the 250-400 that have work.
-// The empty tiles' pixels are written here (zeros; alpha 0 is "not saturated": an empty tile vetoes the global exit).
-__global__ __launch_bounds__(kBlock) void tile_list_kernel(
-    const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int n_tiles, uint32_t* __restrict__ state,
-    uint32_t* __restrict__ work, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
-{
-    __shared__ uint32_t s_empty;
-    if (chunk_base[n_tiles] >= kDeepChunks) return;                                  // a deep view: tile_combine_kernel does all of it
-    const int t0 = blockIdx.x * kListTiles;
-    if (threadIdx.x < 64u) {
-        const int t = t0 + (int)threadIdx.x;
-        const bool valid = threadIdx.x < (uint32_t)kListTiles && t < n_tiles;
-        const bool holds = valid && chunk_base[t + 1] > chunk_base[t];
-        const unsigned long long mh = __builtin_amdgcn_ballot_w64(holds), me = __builtin_amdgcn_ballot_w64(valid && !holds);
-        if (mh) {
-            uint32_t base = 0u;
-            if (threadIdx.x == 0u) base = atomicAdd(work + kWorkNonEmpty, (uint32_t)__popcll(mh));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (holds) list[base + (uint32_t)__popcll(mh & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)t;
-        }
-        if (threadIdx.x == 0u) s_empty = (uint32_t)me;
-    }
-    __syncthreads();
-    uint32_t em = s_empty;            // (the veto of the empty tiles: tile_combine_par_kernel, from the count)
-    const size_t P = (size_t)H * W;
-    while (em) {
-        const int tile = t0 + __builtin_ctz(em);
-        em &= em - 1u;
-        int x, y; pix_xy((int)(threadIdx.x >> 6), (int)(threadIdx.x & 63u), tile % tw, tile / tw, x, y);
-        if (x < W && y < H) {
-            const size_t p = (size_t)y * W + x;
-            rgb[p] = 0.f; rgb[P + p] = 0.f; rgb[2*P + p] = 0.f;
-            alpha[p] = 0.f;
-            if (depth_map) depth_map[p] = 0.f;
-        }
-    }
-}
-
 template <bool DEPTH>
 __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int need_bwd,
@@ -1630,14 +1635,17 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     // fills after the chunk pass (none if the image has more tiles than that holds: then nothing is skipped)
     uint32_t* tile_dark = (could_be_deep && 4 * (size_t)n_tiles <= 4 * (size_t)kWorkClasses * (size_t)max_chunks) ? work + 16 : nullptr;
     // the shallow instantiation only has work below kDeepChunks chunks: its grid need not be larger
-    const dim3 gc((unsigned)max_chunks), gc0((unsigned)(could_be_deep ? kDeepChunks - 1 : max_chunks)), gt((unsigned)n_tiles);
+    const dim3 gc((unsigned)max_chunks), gt((unsigned)n_tiles);
+    // the four-wave chunk pass: one block per chunk, then the blocks that list the non-empty tiles and clear the empty ones' pixels
+    const uint32_t n_list = (uint32_t)((n_tiles + kListTiles - 1) / kListTiles);
+    const dim3 gc0l((unsigned)(could_be_deep ? kDeepChunks - 1 : max_chunks) + n_list);
     uint32_t* hdr = meta + tail_hdr_offset((size_t)max_chunks);                             // published headers, level-order table, payloads
     uint32_t* order_tab = hdr + max_chunks;
     uint32_t* pay = order_tab + max_chunks;
     // shallow views' combine pass: one workgroup per non-empty tile up to kParGrid of them, then a stride
     const dim3 gp((unsigned)std::min<int64_t>(std::min<int64_t>(n_tiles, max_chunks > 0 ? max_chunks : 1), kParGrid));
-    if (max_chunks <= 0) clear_state_kernel<<<dim3(1), dim3(64), 0, st>>>(state, work);     // otherwise block 0 of the chunk pass clears them
-    else if (could_be_deep) {                               // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
+    // (block 0 of the four-wave chunk pass clears state[] and the work counters; with no chunks at all its grid is the list blocks alone)
+    if (could_be_deep) {                               // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
         // the level-order table (its kernel also clears the payloads and the tiles' words), then the header pass: four
         // launches that return at once unless the view at hand is deep.  The grower bitmap (2 words per 64 ranks + the
         // count) borrows the head of the chunk states, which nothing writes before the chunk pass; a model too large
@@ -1654,15 +1662,13 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        if (max_chunks > 0) chunk_fwd_wg_kernel<true><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
+        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_list_kernel<<<dim3((unsigned)((n_tiles + kListTiles - 1) / kListTiles)), dim3(kBlock), 0, st>>>(chunk_base, H, W, tw, n_tiles, state, work, order_tab, rgb, alpha, depth_map);
         tile_combine_par_kernel<true><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
-        if (max_chunks > 0) chunk_fwd_wg_kernel<false><<<gc0, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr);
+        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
-        tile_list_kernel<<<dim3((unsigned)((n_tiles + kListTiles - 1) / kListTiles)), dim3(kBlock), 0, st>>>(chunk_base, H, W, tw, n_tiles, state, work, order_tab, rgb, alpha, depth_map);
         tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     }
