@@ -83,10 +83,18 @@ __device__ __forceinline__ void wave_match_rank(uint32_t d, bool valid, uint32_t
 constexpr int kLossBlocks = 1024;      // partial sums of the image losses (one per workgroup, fixed slices: deterministic)
 int image_loss_fwd_grad_partials(int32_t kind, const float* pred, const float* target, int64_t n, float* d_pred_unit,
                                  void* ws, size_t ws_bytes, void* stream);
+// norm_partials (nullable): one double per workgroup of the kernel, ceil(N / kBlock) of them -- the sum of the squares of the
+// gradients that workgroup wrote (what sumsq_kernel of gsx_optim.hip would have to read back from HBM)
 int preprocess_bwd_with_loss(const float* positions, const float* scales, const float* rotations,
                              const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
                              const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                              int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
-                             float* g_features, const double* loss_partials, int64_t loss_n, float* loss, void* stream);
+                             float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials, void* stream);
+int clip_adam_step_impl(int32_t n_tensors, float* const* params_host, float* const* grads_host,
+                        float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                        const int64_t* numel_host, const float* lr_host,
+                        float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                        int32_t write_clipped_grad, void* ws, size_t ws_bytes, const double* norm_partials, int32_t n_norm_partials,
+                        void* stream);
 
 }  // namespace gsx

@@ -37,6 +37,11 @@ __device__ __forceinline__ int find_tensor(const AdamArgs& a, long long i)
     return t;
 }
 
+__device__ __forceinline__ double sq4(const float4& x)
+{
+    return ((double)x.x * (double)x.x + (double)x.y * (double)x.y) + ((double)x.z * (double)x.z + (double)x.w * (double)x.w);
+}
+
 // partial sums of squares over contiguous slices of the 4-element groups (fixed slicing -> deterministic)
 __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __restrict__ partials)
 {
@@ -44,7 +49,10 @@ __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __res
     const long long total = a.qbegin[a.n_tensors];
     const long long per = (total + kNormBlocks - 1) / kNormBlocks;
     const long long lo = (long long)blockIdx.x * per, hi = min(lo + per, total);
-    float s = 0.0f;
+    // squares and sums in DOUBLE (a float's square is exact in a double; the sums then differ between two ways of cutting the
+    // buffer by ~1e-16 relative, far below the float the norm is rounded to): the one-call trainer step takes its partial sums
+    // from preprocess_bwd's workgroups instead of this kernel (gsx_view.hip) and must arrive at the same coefficient
+    double s = 0.0;
     // the slice usually lies inside one tensor: walk the tensors it meets, so that the inner loop is nothing but
     // independent 16-byte loads (4 in flight per thread) -- with the tensor lookup inside it the loop ran one load at a time
     for (int t = 0; t < a.n_tensors; t++) {
@@ -58,18 +66,15 @@ __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __res
         long long q = qlo + threadIdx.x;
         for (; q + 3 * kBlock < vhi; q += 4 * kBlock) {
             const float4 x0 = g4[q], x1 = g4[q + kBlock], x2 = g4[q + 2 * kBlock], x3 = g4[q + 3 * kBlock];
-            s += (x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w);
-            s += (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
-            s += (x2.x * x2.x + x2.y * x2.y) + (x2.z * x2.z + x2.w * x2.w);
-            s += (x3.x * x3.x + x3.y * x3.y) + (x3.z * x3.z + x3.w * x3.w);
+            s += sq4(x0); s += sq4(x1); s += sq4(x2); s += sq4(x3);
         }
-        for (; q < vhi; q += kBlock) { const float4 x = g4[q]; s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w); }
+        for (; q < vhi; q += kBlock) s += sq4(g4[q]);
         for (q = (qlo > full ? qlo : full) + threadIdx.x; q < qhi; q += kBlock) {      // unaligned tensors and the ragged last group
             const long long j = (q - a.qbegin[t]) * 4;
-            for (int k = 0; k < 4 && j + k < n; k++) s += g[j + k] * g[j + k];
+            for (int k = 0; k < 4 && j + k < n; k++) s += (double)g[j + k] * (double)g[j + k];
         }
     }
-    double sd = (double)s;
+    double sd = s;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sd += __shfl_down(sd, d, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sd;
@@ -80,11 +85,11 @@ __global__ __launch_bounds__(kBlock) void sumsq_kernel(AdamArgs a, double* __res
 // total_norm and clip coefficient = min(1, max_norm / (total_norm + 1e-6)) from the kNormBlocks partial sums.  Every
 // workgroup of the update kernel runs it itself (same values, same order -> the same bits everywhere): 8 KB of
 // L2 reads per workgroup instead of a separate one-workgroup launch between the two passes.
-__device__ __forceinline__ float clip_coefficient(const double* __restrict__ partials, float max_norm, float* norm_out)
+__device__ __forceinline__ float clip_coefficient(const double* __restrict__ partials, int n_partials, float max_norm, float* norm_out)
 {
     __shared__ double s_v[kBlock];
     double s = 0.0;
-    for (int i = threadIdx.x; i < kNormBlocks; i += kBlock) s += partials[i];
+    for (int i = threadIdx.x; i < n_partials; i += kBlock) s += partials[i];
     s_v[threadIdx.x] = s;
     __syncthreads();
     for (int d = kBlock / 2; d > 0; d >>= 1) { if (threadIdx.x < d) s_v[threadIdx.x] += s_v[threadIdx.x + d]; __syncthreads(); }
@@ -105,7 +110,7 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
     p = p + neg_step * (m / denom);          // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
-__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const double* __restrict__ partials, float max_norm,
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const double* __restrict__ partials, int n_partials, float max_norm,
                                                       float* __restrict__ norm_coef_out, int write_clipped_grad,
                                                       float beta1, float beta2, float eps, float bc2_sqrt)
 {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const double* 
     float coef = 1.0f;
     if (clip) {
         float norm;
-        coef = clip_coefficient(partials, max_norm, &norm);
+        coef = clip_coefficient(partials, n_partials, max_norm, &norm);
         if (blockIdx.x == 0 && threadIdx.x == 0) { norm_coef_out[0] = norm; norm_coef_out[1] = coef; }
     }
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
@@ -149,11 +154,14 @@ using namespace gsx;
 
 GSX_API size_t gsx_clip_adam_workspace_bytes(void) { return (size_t)kNormBlocks * 8 + 256; }
 
-GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, float* const* grads_host,
-                               float* const* exp_avg_host, float* const* exp_avg_sq_host,
-                               const int64_t* numel_host, const float* lr_host,
-                               float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
-                               int32_t write_clipped_grad, void* ws, size_t ws_bytes, void* stream)
+// n_norm_partials > 0: the sums of squares are already there (norm_partials, that many doubles: the one-call trainer step's
+// preprocess_bwd left one per workgroup) and the first launch is left out
+int gsx::clip_adam_step_impl(int32_t n_tensors, float* const* params_host, float* const* grads_host,
+                             float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                             const int64_t* numel_host, const float* lr_host,
+                             float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                             int32_t write_clipped_grad, void* ws, size_t ws_bytes, const double* norm_partials, int32_t n_norm_partials,
+                             void* stream)
 {
     if (n_tensors <= 0 || n_tensors > kMaxTensors || step <= 0) return GSX_E_INVALID;
     if (!params_host || !grads_host || !exp_avg_host || !exp_avg_sq_host || !numel_host || !lr_host) return GSX_E_INVALID;
@@ -175,16 +183,30 @@ GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, flo
     const long long total = a.begin[n_tensors];
     if (total == 0) return GSX_OK;
     hipStream_t st = (hipStream_t)stream;
-    double* partials = nullptr;
+    const double* partials = nullptr;
+    int n_partials = 0;
     float* norm_coef = nullptr;
     if (max_grad_norm > 0.0f) {
-        partials = (double*)ws;
         norm_coef = (float*)((char*)ws + (size_t)kNormBlocks * 8);
-        sumsq_kernel<<<dim3(kNormBlocks), dim3(kBlock), 0, st>>>(a, partials);
+        if (n_norm_partials > 0 && norm_partials) { partials = norm_partials; n_partials = n_norm_partials; }
+        else {
+            sumsq_kernel<<<dim3(kNormBlocks), dim3(kBlock), 0, st>>>(a, (double*)ws);
+            partials = (const double*)ws; n_partials = kNormBlocks;
+        }
     }
     const long long blocks = ceil_div(a.qbegin[n_tensors], kBlock);
     adam_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0, st>>>(
-        a, partials, max_grad_norm, norm_coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
+        a, partials, n_partials, max_grad_norm, norm_coef, write_clipped_grad, beta1, beta2, eps, (float)sqrt(bc2));
     GSX_LAUNCH_CHECK();
     return GSX_OK;
+}
+
+GSX_API int gsx_clip_adam_step(int32_t n_tensors, float* const* params_host, float* const* grads_host,
+                               float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                               const int64_t* numel_host, const float* lr_host,
+                               float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                               int32_t write_clipped_grad, void* ws, size_t ws_bytes, void* stream)
+{
+    return gsx::clip_adam_step_impl(n_tensors, params_host, grads_host, exp_avg_host, exp_avg_sq_host, numel_host, lr_host, beta1, beta2, eps,
+                                    step, max_grad_norm, write_clipped_grad, ws, ws_bytes, nullptr, 0, stream);
 }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float* __restrict__ d_mean2d, const float* __restrict__ d_depth, const float* __restrict__ d_cov2d,
     int N, int accumulate,
     float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea,
-    const double* __restrict__ loss_partials, long long loss_n, float* __restrict__ loss)
+    const double* __restrict__ loss_partials, long long loss_n, float* __restrict__ loss, double* __restrict__ norm_partials)
 {
     if (loss && blockIdx.x == gridDim.x - 1) {
         // the one-call trainer step's loss value: gsx_loss.hip's loss_final_kernel, same order of summation (same bits), by
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         for (int d = kBlock / 2; d > 0; d >>= 1) { if (threadIdx.x < d) s_v[threadIdx.x] += s_v[threadIdx.x + d]; __syncthreads(); }
         if (threadIdx.x == 0) loss[0] = (float)(s_v[0] / (double)loss_n);
     }
-    const int g = blockIdx.x * kBlock + threadIdx.x;        // N is rounded up to whole waves below: no early return before the shuffles
+    int g = blockIdx.x * kBlock + threadIdx.x;              // N is rounded up to whole waves below: no early return before the shuffles
     const int lane = threadIdx.x & 63;
     const bool live = g < N;
     const uint32_t r = live ? rank_of[g] : 0u;
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
             if (lane == src) D[c] = S[c];
         }
     }
-    if (!live) return;
+    if (!live && !norm_partials) return;
+    const int gl = g;                          // (stores)
+    g = live ? g : N - 1;                      // a thread past the end only takes part in the workgroup's sum of squares below
     float M[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) M[k] = pose[k];
@@ -350,17 +352,37 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float dcam[3] = { dmx / cz, dmy / cz, -(dmx * o.cam[0] + dmy * o.cam[1]) / (cz * cz) + (d_depth ? d_depth[g] : 0.0f) };
 #pragma unroll
     for (int j = 0; j < 3; j++) gp[j] += dcam[0]*M[0*4+j] + dcam[1]*M[1*4+j] + dcam[2]*M[2*4+j];
-    if (accumulate) {
+    if (live) {
+        if (accumulate) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) { g_pos[3*g+j] += gp[j]; g_scl[3*g+j] += gs[j]; g_fea[3*g+j] += D[6+j]; }
+            for (int j = 0; j < 3; j++) { g_pos[3*gl+j] += gp[j]; g_scl[3*gl+j] += gs[j]; g_fea[3*gl+j] += D[6+j]; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) g_rot[4*g+j] += gq[j];
-        g_opa[g] += D[5];
-    } else {
+            for (int j = 0; j < 4; j++) g_rot[4*gl+j] += gq[j];
+            g_opa[gl] += D[5];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 3; j++) { g_pos[3*g+j] = gp[j]; g_scl[3*g+j] = gs[j]; g_fea[3*g+j] = D[6+j]; }
-        reinterpret_cast<float4*>(g_rot)[g] = make_float4(gq[0], gq[1], gq[2], gq[3]);
-        g_opa[g] = D[5];
+            for (int j = 0; j < 3; j++) { g_pos[3*gl+j] = gp[j]; g_scl[3*gl+j] = gs[j]; g_fea[3*gl+j] = D[6+j]; }
+            reinterpret_cast<float4*>(g_rot)[gl] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+            g_opa[gl] = D[5];
+        }
+    }
+    if (norm_partials) {
+        // the clip norm's sum of squares over what this workgroup just wrote (accumulate == 0), in double like sumsq_kernel:
+        // the one-call trainer step's optimizer reads these instead of the 56 N bytes of gradients
+        __shared__ double s_nw[kBlock / 64];
+        double sq = 0.0;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) sq += (double)gp[j] * (double)gp[j] + (double)gs[j] * (double)gs[j] + (double)D[6+j] * (double)D[6+j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sq += (double)gq[j] * (double)gq[j];
+            sq += (double)D[5] * (double)D[5];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d, 64);
+        if (lane == 0) s_nw[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) norm_partials[blockIdx.x] = (s_nw[0] + s_nw[1]) + (s_nw[2] + s_nw[3]);
     }
 }
 
@@ -418,7 +440,7 @@ GSX_API int gsx_preprocess_bwd(const float* positions, const float* scales, cons
     if (d_cov2d && ((uintptr_t)d_cov2d & 15u)) return GSX_E_INVALID;
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
-        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features, nullptr, 0, nullptr);
+        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features, nullptr, 0, nullptr, nullptr);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -429,7 +451,8 @@ int gsx::preprocess_bwd_with_loss(const float* positions, const float* scales, c
                                   const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
                                   const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                                   int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
-                                  float* g_features, const double* loss_partials, int64_t loss_n, float* loss, void* stream)
+                                  float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials,
+                                  void* stream)
 {
     if (N <= 0) return GSX_E_INVALID;
     if (!positions || !scales || !rotations || !pose || !rank_of || !offsets || !tiles_touched || !partials) return GSX_E_INVALID;
@@ -438,7 +461,8 @@ int gsx::preprocess_bwd_with_loss(const float* positions, const float* scales, c
     if (loss && (!loss_partials || loss_n <= 0)) return GSX_E_INVALID;
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
-        nullptr, nullptr, nullptr, N, 0, g_positions, g_scales, g_rotations, g_opacity, g_features, loss_partials, (long long)loss_n, loss);
+        nullptr, nullptr, nullptr, N, 0, g_positions, g_scales, g_rotations, g_opacity, g_features, loss_partials, (long long)loss_n, loss,
+        norm_partials);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -159,7 +159,17 @@ static int check_step(const gsx_step* s, bool grads, bool apply)
 // The step in its two halves, for data-parallel ranks: everything up to the gradients (the flat buffer the caller hands
 // in through grad[]), then -- after the caller's one collective on the same stream -- clip + Adam.  gsx_train_step is
 // the two back to back.
-GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream)
+// where the one-call step keeps the clip norm's partial sums (one double per workgroup of preprocess_bwd) when the caller's Adam
+// workspace has room for them behind what gsx_clip_adam_step uses; nullptr: the optimizer half computes the norm itself
+static double* folded_norm_partials(const gsx_step* s)
+{
+    const size_t base = gsx_clip_adam_workspace_bytes();
+    const size_t need = base + (size_t)gsx::ceil_div(s->N, gsx::kBlock) * sizeof(double);
+    if (!(s->max_grad_norm > 0.0f) || !s->adam_ws || s->adam_ws_bytes < need) return nullptr;
+    return reinterpret_cast<double*>(static_cast<char*>(s->adam_ws) + base);
+}
+
+static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void* stream)
 {
     int st = check_step(s, true, false);
     if (st != GSX_OK) return st;
@@ -200,10 +210,17 @@ GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream)
     return gsx::preprocess_bwd_with_loss(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),
                                     u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, s->N,
                                     s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4],
-                                    fold_loss ? static_cast<const double*>(s->loss_ws) : nullptr, px, fold_loss ? s->loss : nullptr, stream);
+                                    fold_loss ? static_cast<const double*>(s->loss_ws) : nullptr, px, fold_loss ? s->loss : nullptr,
+                                    norm_partials, stream);
 }
 
-GSX_API int gsx_train_step_apply(const gsx_step* s, void* stream)
+GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream) { return train_step_grads_impl(s, nullptr, stream); }
+
+static int train_step_apply_impl(const gsx_step* s, const double* norm_partials, void* stream);
+
+GSX_API int gsx_train_step_apply(const gsx_step* s, void* stream) { return train_step_apply_impl(s, nullptr, stream); }
+
+static int train_step_apply_impl(const gsx_step* s, const double* norm_partials, void* stream)
 {
     const int st = check_step(s, false, true);
     if (st != GSX_OK) return st;
@@ -215,15 +232,17 @@ GSX_API int gsx_train_step_apply(const gsx_step* s, void* stream)
         p[k] = s->param[t]; g[k] = s->grad[t]; m[k] = s->exp_avg[t]; v[k] = s->exp_avg_sq[t]; lr[k] = s->lr[t];
         numel[k] = per_row[t] * s->N;
     }
-    return gsx_clip_adam_step(5, p, g, m, v, numel, lr, s->beta1, s->beta2, s->eps, s->step, s->max_grad_norm, s->write_clipped_grad,
-                              s->adam_ws, s->adam_ws_bytes, stream);
+    return gsx::clip_adam_step_impl(5, p, g, m, v, numel, lr, s->beta1, s->beta2, s->eps, s->step, s->max_grad_norm, s->write_clipped_grad,
+                                    s->adam_ws, s->adam_ws_bytes, norm_partials, norm_partials ? (int32_t)gsx::ceil_div(s->N, gsx::kBlock) : 0, stream);
 }
 
 GSX_API int gsx_train_step(const gsx_step* s, void* stream)
 {
     int st = check_step(s, true, true);
     if (st != GSX_OK) return st;
-    st = gsx_train_step_grads(s, stream);
+    // nothing stands between the two halves here (no exchange): the clip norm's sums of squares ride on the last backward kernel
+    double* norm_partials = folded_norm_partials(s);
+    st = train_step_grads_impl(s, norm_partials, stream);
     if (st != GSX_OK) return st;
-    return gsx_train_step_apply(s, stream);
+    return train_step_apply_impl(s, norm_partials, stream);
 }

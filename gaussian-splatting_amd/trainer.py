@@ -190,8 +190,11 @@ class FusedTrainStep:
             S.exp_avg[k] = st['exp_avg'].data_ptr(); S.exp_avg_sq[k] = st['exp_avg_sq'].data_ptr()
             S.lr[k] = float(opt.param_groups[self.group_of[id(p)]]['lr'])
         S.step = step + 1
-        if opt._ws is None or opt._ws.device != dev:
-            opt._ws = torch.empty(L.lib().gsx_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # room behind the optimizer's own workspace for one double per 256 Gaussians: gsx_train_step then takes the clip norm's sums
+        # of squares from the last backward kernel instead of reading the gradients back (gsx.h)
+        ws_need = L.lib().gsx_clip_adam_workspace_bytes() + 8 * ((self.n + 255) // 256)
+        if opt._ws is None or opt._ws.device != dev or opt._ws.numel() < ws_need:
+            opt._ws = torch.empty(ws_need, dtype=torch.uint8, device=dev)
         S.adam_ws, S.adam_ws_bytes = opt._ws.data_ptr(), opt._ws.numel()
         loss = torch.empty(3, dtype=torch.float32, device=dev)           # fresh per step: the caller may keep what is returned
         S.loss, S.pose, S.target = loss.data_ptr(), pose.data_ptr(), target.data_ptr()

@@ -315,7 +315,10 @@ int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int3
  * the count check described above, both backward stages) and leaves them in grad[] -- five views of ONE flat buffer when
  * the caller lays them out that way -- and _apply enqueues gsx_clip_adam_step; the caller issues its one collective over
  * the gradient buffer on the same stream between the two.  _grads ignores the Adam fields (exp_avg, exp_avg_sq, lr,
- * betas, step), _apply reads only those, param, grad, adam_order, N and the workspace.  gsx_train_step == _grads; _apply. */
+ * betas, step), _apply reads only those, param, grad, adam_order, N and the workspace.  gsx_train_step == _grads; _apply --
+ * with one launch less when adam_ws has room for one double per 256 Gaussians behind gsx_clip_adam_workspace_bytes() (adam_ws_bytes
+ * >= that + 8 * ceil(N / 256)): the clip norm's sums of squares are then left there by the last backward kernel instead of a
+ * pass of their own over the gradients.  Both ways sum exact squares in double, so the coefficient is the same float. */
 #define GSX_LOSS_L1_SSIM 2
 typedef struct gsx_step {
     float* param[5];               /* updated in place */
@@ -342,7 +345,7 @@ typedef struct gsx_step {
     float* d_rgb;                  /* 3 x H x W floats of scratch: dLoss/drgb */
     float* loss;                   /* 3 floats: [0] the criterion; GSX_LOSS_L1_SSIM also writes [1] = L1, [2] = SSIM */
     void* loss_ws; size_t loss_ws_bytes;   /* gsx_image_loss_workspace_bytes() or gsx_l1_ssim_workspace_bytes(3, H, W) */
-    void* adam_ws; size_t adam_ws_bytes;   /* gsx_clip_adam_workspace_bytes() */
+    void* adam_ws; size_t adam_ws_bytes;   /* gsx_clip_adam_workspace_bytes() (+ 8 * ceil(N / 256), see above) */
     int64_t* counts_pinned_host;   /* 2 x i64 of pinned host memory: D, mismatch count */
     void* count_event;             /* hipEvent_t */
 } gsx_step;
