@@ -197,7 +197,8 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                   const uint64_t* __restrict__ total_dev, int64_t capacity, int n_tiles,
                                                                   const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
-                                                                  int chunk_force, uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base)
+                                                                  int chunk_force, uint32_t* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
+                                                                  uint64_t* __restrict__ info)
 {
     __shared__ uint16_t s_cnt[kTsWaves][kTsDigits];      // per-wave digit counts, then per-wave offsets inside the workgroup
     __shared__ uint32_t s_base[kTsDigits];               // per tile: global slot minus position inside the workgroup
@@ -243,6 +244,17 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
 #pragma unroll
         for (int i = 0; i < 4; i++) { const int d = 4 * tid + i; if (d < n_tiles) chunk_base[d] = cex; cex += cc[i]; }
         if (tid == 0) { chunk_base[n_tiles] = ctot; chunk_base[n_tiles + 1] = ch; }
+        if (info) {
+            // for the one-call trainer step (gsx_view.hip): 1 + the number of EMPTY tiles, straight into the host's pinned word.  An
+            // empty tile's pixels stay at alpha 0, so the reference's global early exit cannot fire on this view, and the host,
+            // which reads this with the instance count, leaves the exit path's three launches out
+            uint32_t etot;
+            uint32_t ne = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) ne += (4 * tid + i < n_tiles && tv[i] == 0u) ? 1u : 0u;
+            block1024_excl_scan(ne, s_scan, &etot);
+            if (tid == 0) info[0] = 1ull + (uint64_t)etot;
+        }
         if (!active) return;
     }
     const uint32_t* prow = hist_scanned + (size_t)blockIdx.x * kTsDigits;
@@ -651,6 +663,16 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box, const 
                               uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
                               uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream)
 {
+    return gsx::bin_emit_sort_impl(rec, tile_box, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
+                                   ranges, chunk_base, chunk_force, ws, ws_bytes, nullptr, stream);
+}
+
+// info (nullable, device-visible pinned host memory): images of up to 4096 tiles leave 1 + their number of empty tiles there
+int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                            int64_t capacity, const uint64_t* total_dev,
+                            uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                            uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream)
+{
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity <= 0) return GSX_E_INVALID;
     if (chunk_force != 0 && chunk_force != 64 && chunk_force != 128 && chunk_force != 256) return GSX_E_INVALID;
     if (capacity >= 0xFFFFFFFFll) return GSX_E_RANGE;
@@ -678,7 +700,7 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box, const 
         }
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
         tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
-                                                                    hist, totals, chunk_force, ranges, chunk_base);
+                                                                    hist, totals, chunk_force, ranges, chunk_base, info);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
     }

@@ -90,6 +90,16 @@ int preprocess_bwd_with_loss(const float* positions, const float* scales, const 
                              const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                              int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
                              float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials, void* stream);
+// gsx_bin_emit_sort with a pinned host word for the number of empty tiles; gsx_composite_fwd in two parts (which: 1 = the view's
+// compositing, 2 = the global-exit path behind it -- search, second chunk pass, second combine pass --, 3 = both)
+int bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                       int64_t capacity, const uint64_t* total_dev,
+                       uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
+                       uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream);
+int composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                       const uint32_t* chunk_base, int32_t N, int32_t H, int32_t W,
+                       int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,
+                       float* rgb, float* alpha, float* depth_map, int which, void* stream);
 int clip_adam_step_impl(int32_t n_tensors, float* const* params_host, float* const* grads_host,
                         float* const* exp_avg_host, float* const* exp_avg_sq_host,
                         const int64_t* numel_host, const float* lr_host,

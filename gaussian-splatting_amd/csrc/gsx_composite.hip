@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     const uint32_t n_held = work[kWorkNonEmpty];
     // alpha = 0 on an empty tile is "not saturated": it vetoes the global exit (one workgroup says so for all of them; a
     // look-and-raise per empty tile was 3700 reads of one L2 line)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n_held < (uint32_t)n_tiles) atomicOr(state + 1, 1u);
+    // (and says "no exit rank" itself: the search behind this launch would, but the one-call trainer step does not even enqueue it
+    // when the host knows of an empty tile -- gsx_view.hip)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_held < (uint32_t)n_tiles) { atomicOr(state + 1, 1u); state[0] = GSX_RANK_NONE; }
     for (uint32_t item = blockIdx.x; item < n_held; item += gridDim.x) {
     const int tile = (int)list[item];
     const uint32_t c0 = chunk_base[tile], c1 = chunk_base[tile + 1];
@@ -1617,6 +1619,15 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
                               int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,
                               float* rgb, float* alpha, float* depth_map, void* stream)
 {
+    return gsx::composite_fwd_impl(rec, ranks_sorted, ranges, chunk_base, N, H, W, max_chunks, chunk_state, need_bwd, state, rgb, alpha, depth_map,
+                                   3, stream);
+}
+
+int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                            const uint32_t* chunk_base, int32_t N, int32_t H, int32_t W,
+                            int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,
+                            float* rgb, float* alpha, float* depth_map, int which, void* stream)
+{
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
     if (!ranges || !chunk_base || !state || !rgb || !alpha) return GSX_E_INVALID;
     // an empty model (N == 0) has no records: every tile's list is empty, the chunk table says 0 chunks, nothing reads `rec`
@@ -1644,6 +1655,7 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
     uint32_t* pay = order_tab + max_chunks;
     // shallow views' combine pass: one workgroup per non-empty tile up to kParGrid of them, then a stride
     const dim3 gp((unsigned)std::min<int64_t>(std::min<int64_t>(n_tiles, max_chunks > 0 ? max_chunks : 1), kParGrid));
+    if (which & 1) {
     // (block 0 of the four-wave chunk pass clears state[] and the work counters; with no chunks at all its grid is the list blocks alone)
     if (could_be_deep) {                               // (max_chunks bounds the view's chunk count: below the threshold no view can be deep)
         // the level-order table (its kernel also clears the payloads and the tiles' words), then the header pass: four
@@ -1672,6 +1684,8 @@ GSX_API int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, co
         tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     }
+    }
+    if (!(which & 2)) { GSX_LAUNCH_CHECK(); return GSX_OK; }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);

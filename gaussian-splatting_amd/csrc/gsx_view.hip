@@ -80,6 +80,18 @@ GSX_API int64_t gsx_view_layout(int32_t N, int32_t H, int32_t W, int64_t capacit
     return L.bytes;
 }
 
+// late = 0: the public call.  late = 1 (the one-call trainer step): D_pinned_host has FOUR words, the third receives 1 + the number of
+// empty tiles from the tile sort (0 stays for "not known": images of more than 4096 tiles), the event is recorded behind the tile
+// sort instead of behind the count, and the global-exit path's three launches are left to the caller (composite_fwd_impl, which = 2),
+// who knows by then whether the view can saturate at all.
+static int view_forward_impl(const float* positions, const float* scales, const float* rotations,
+                             const float* opacity, const float* features, const float* pose,
+                             int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t depth_bits,
+                             const uint32_t* given_order, int32_t need_bwd, int32_t chunk_force,
+                             void* arena, int64_t arena_bytes,
+                             float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
+                             uint32_t* state, int64_t* D_pinned_host, void* count_event, int late, void* stream);
+
 GSX_API int gsx_view_forward(const float* positions, const float* scales, const float* rotations,
                              const float* opacity, const float* features, const float* pose,
                              int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t depth_bits,
@@ -87,6 +99,19 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              void* arena, int64_t arena_bytes,
                              float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
                              uint32_t* state, int64_t* D_pinned_host, void* count_event, void* stream)
+{
+    return view_forward_impl(positions, scales, rotations, opacity, features, pose, N, H, W, capacity, depth_bits, given_order, need_bwd,
+                             chunk_force, arena, arena_bytes, mean2d, depth, cov2d, rgb, alpha, depth_map, state, D_pinned_host, count_event,
+                             0, stream);
+}
+
+static int view_forward_impl(const float* positions, const float* scales, const float* rotations,
+                             const float* opacity, const float* features, const float* pose,
+                             int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t depth_bits,
+                             const uint32_t* given_order, int32_t need_bwd, int32_t chunk_force,
+                             void* arena, int64_t arena_bytes,
+                             float* mean2d, float* depth, float* cov2d, float* rgb, float* alpha, float* depth_map,
+                             uint32_t* state, int64_t* D_pinned_host, void* count_event, int late, void* stream)
 {
     if (!positions || !scales || !rotations || !opacity || !features || !pose || !arena || !rgb || !alpha || !state)
         return GSX_E_INVALID;
@@ -123,15 +148,22 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
     if (st != GSX_OK) return st;
     // the host may read D (and the sort's mismatch count) as soon as THIS point of the stream is reached, long before the
     // compositing enqueued below has run
-    if (count_event) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
-    st = gsx_bin_emit_sort(f32(GSX_VIEW_REC), u32(GSX_VIEW_TILE_BOX), u32(GSX_VIEW_OFFSETS), N, H, W, capacity, total,
-                           u32(GSX_VIEW_TILES_SORTED), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_TILES_TMP), u32(GSX_VIEW_RANKS_TMP),
-                           u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), chunk_force,
-                           raw(GSX_VIEW_BIN_WS), gsx_bin_workspace_bytes(N, capacity), stream);
+    if (count_event && !late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
+    uint64_t* info = nullptr;
+    if (late && D_pinned_host && N > 0) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, D_pinned_host, 0) == hipSuccess) info = static_cast<uint64_t*>(dp) + 2;
+        else (void)hipGetLastError();
+    }
+    st = gsx::bin_emit_sort_impl(f32(GSX_VIEW_REC), u32(GSX_VIEW_TILE_BOX), u32(GSX_VIEW_OFFSETS), N, H, W, capacity, total,
+                                 u32(GSX_VIEW_TILES_SORTED), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_TILES_TMP), u32(GSX_VIEW_RANKS_TMP),
+                                 u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), chunk_force,
+                                 raw(GSX_VIEW_BIN_WS), gsx_bin_workspace_bytes(N, capacity), info, stream);
     if (st != GSX_OK) return st;
-    return gsx_composite_fwd(f32(GSX_VIEW_REC), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), N, H, W,
-                             L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, state,
-                             rgb, alpha, depth_map, stream);
+    if (count_event && late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
+    return gsx::composite_fwd_impl(f32(GSX_VIEW_REC), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), N, H, W,
+                                   L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, state,
+                                   rgb, alpha, depth_map, late ? 1 : 3, stream);
 }
 
 // One trainer step of one view: the view's forward above, the criterion, the two backward stages and the fused
@@ -176,10 +208,34 @@ static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void*
     Layout L;
     st = make_layout(s->N, s->H, s->W, s->capacity, s->chunk_force, 1, L);
     if (st != GSX_OK) return st;
-    st = gsx_view_forward(s->param[0], s->param[1], s->param[2], s->param[3], s->param[4], s->pose, s->N, s->H, s->W, s->capacity,
-                          s->depth_bits, nullptr, 1, s->chunk_force, s->arena, s->arena_bytes, s->mean2d, s->depth, s->cov2d,
-                          s->rgb, s->alpha, nullptr, s->state, s->counts_pinned_host, s->count_event, stream);
+    s->counts_pinned_host[2] = 0;                 // "number of empty tiles not known" until the tile sort says otherwise
+    st = view_forward_impl(s->param[0], s->param[1], s->param[2], s->param[3], s->param[4], s->pose, s->N, s->H, s->W, s->capacity,
+                           s->depth_bits, nullptr, 1, s->chunk_force, s->arena, s->arena_bytes, s->mean2d, s->depth, s->cov2d,
+                           s->rgb, s->alpha, nullptr, s->state, s->counts_pinned_host, s->count_event, 1, stream);
     if (st != GSX_OK) return st;
+    // The verdict on this step's optimism, BEFORE anything behind the view's compositing is enqueued: a forward whose buffers were
+    // too small is truncated but in bounds, while the backward would follow offsets[] (which count every instance) past the end of
+    // the partial rows.  The event sits behind the tile sort: the GPU is compositing the view when the host gets here, and has
+    // the chunk pass and the combine pass in front of it while the host enqueues the rest of the step.
+    GSX_HIP(hipEventSynchronize(static_cast<hipEvent_t>(s->count_event)));
+    const int64_t D = s->counts_pinned_host[0], mismatch = s->counts_pinned_host[1], tiles_info = s->counts_pinned_host[2];
+    if (D >= 0xFFFFFFFFll) return GSX_E_RANGE;
+    if (D > s->capacity) return GSX_E_CAPACITY;
+    if (s->depth_bits < 32 && mismatch != 0) return GSX_E_AGAIN;
+    char* arena = static_cast<char*>(s->arena);
+    auto u32 = [&](int slot) { return reinterpret_cast<const uint32_t*>(arena + L.off[slot]); };
+    const float* rec = reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_REC]);
+    // the reference's global early exit (all pixels saturated at once) cannot fire on a view that leaves a tile empty: the exit
+    // path's three launches -- no-ops then, 4.5 us of launch floor each -- are only enqueued when no tile is known to be empty
+    // (shallow views only: theirs is the combine pass that writes "no exit rank" next to the empty tiles' veto)
+    const int64_t n_tiles = (int64_t)((s->W + GSX_TILE - 1) / GSX_TILE) * ((s->H + GSX_TILE - 1) / GSX_TILE);
+    const bool shallow = D / (int64_t)gsx::chunk_size_for((uint64_t)D, s->chunk_force) + n_tiles + 1 < (int64_t)GSX_DEEP_CHUNKS;
+    if (tiles_info <= 1 || !shallow) {
+        st = gsx::composite_fwd_impl(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), s->N, s->H, s->W,
+                                     L.max_chunks, reinterpret_cast<float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), 1, s->state,
+                                     s->rgb, s->alpha, nullptr, 2, stream);
+        if (st != GSX_OK) return st;
+    }
     const int64_t px = 3ll * s->H * s->W;
     if (s->loss_kind == GSX_LOSS_L1_SSIM) {
         st = gsx_l1_ssim_fwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, s->loss, s->loss_ws, s->loss_ws_bytes, stream);
@@ -190,17 +246,6 @@ static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void*
         st = gsx::image_loss_fwd_grad_partials(s->loss_kind, s->rgb, s->target, px, s->d_rgb, s->loss_ws, s->loss_ws_bytes, stream);
     }
     if (st != GSX_OK) return st;
-    // The verdict on this step's optimism, BEFORE the backward is enqueued: a forward whose buffers were too small is
-    // truncated but in bounds, while the backward would follow offsets[] (which count every instance) past the end of the
-    // partial rows.  The GPU is still binning and compositing the view when the host gets here, so the wait is short or none.
-    GSX_HIP(hipEventSynchronize(static_cast<hipEvent_t>(s->count_event)));
-    const int64_t D = s->counts_pinned_host[0], mismatch = s->counts_pinned_host[1];
-    if (D >= 0xFFFFFFFFll) return GSX_E_RANGE;
-    if (D > s->capacity) return GSX_E_CAPACITY;
-    if (s->depth_bits < 32 && mismatch != 0) return GSX_E_AGAIN;
-    char* arena = static_cast<char*>(s->arena);
-    auto u32 = [&](int slot) { return reinterpret_cast<const uint32_t*>(arena + L.off[slot]); };
-    const float* rec = reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_REC]);
     float* partials = reinterpret_cast<float*>(arena + L.off[GSX_VIEW_PARTIALS]);
     st = gsx_composite_bwd(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), u32(GSX_VIEW_OFFSETS),
                            s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,

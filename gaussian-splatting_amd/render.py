@@ -90,7 +90,7 @@ class _Scratch:
         count; one per stream, so that views in flight on different streams (render_orbit) do not share it"""
         key = (dev, L.stream_ptr())
         if key not in self.pinned:
-            self.pinned[key] = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+            self.pinned[key] = (torch.zeros(4, dtype=torch.int64).pin_memory(), torch.cuda.Event())    # (D, mismatch count; gsx_train_step: + empty tiles)
         return self.pinned[key]
 
     def count_slot_raw(self, dev):

@@ -303,12 +303,15 @@ int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int3
  * Tensors are indexed 0..4 = positions, scales, rotations, opacity, features.  adam_order[k] = which tensor
  * gsx_clip_adam_step sees k-th (the clip norm's partial sums follow that order; the reference's optimizer groups are
  * positions, features, scales, rotations, opacity = {0, 4, 1, 2, 3}, trainer.py:49-61).
- * Before the backward is enqueued the call waits for count_event (recorded in the middle of the forward: the GPU is
- * busy with the rest of the forward meanwhile) and reads the two pinned words: D > capacity returns GSX_E_CAPACITY,
+ * Behind the view's compositing launches the call waits for count_event (recorded behind the tile sort: the GPU has the chunk
+ * pass and the combine pass in front of it meanwhile) and reads the pinned words: D > capacity returns GSX_E_CAPACITY,
  * depth_bits < 32 with a non-zero mismatch count returns GSX_E_AGAIN (retry with depth_bits = 32) -- in both cases
- * neither the backward nor the optimizer was enqueued: gradients, parameters and Adam state are untouched (rgb and *loss
- * are those of the truncated / mis-sorted view); the caller grows the block / widens the sort and calls again with the
- * same `step`.  GSX_OK: the step is enqueued whole.
+ * neither the criterion, the backward nor the optimizer was enqueued: gradients, parameters and Adam state are untouched (rgb
+ * is that of the truncated / mis-sorted view); the caller grows the block / widens the sort and calls again with the
+ * same `step`.  GSX_OK: the step is enqueued whole.  The third word is why the event sits where it does: the tile sort writes
+ * 1 + the number of EMPTY tiles there (images of up to 4096 tiles), and a view that leaves a tile empty cannot take the
+ * reference's global early exit (that tile's pixels stay at alpha 0) -- gsx_composite_fwd's exit path, three launches that
+ * would find nothing to do, is then not enqueued at all.  Same results either way.
  * gsx_train_step_grads / gsx_train_step_apply are the step's two halves, for data-parallel ranks (the reference wraps the
  * model in DistributedDataParallel, scripts/train.py:134-139: the gradient average sits between backward and
  * clip_grad_norm_, training/trainer.py:166-175): _grads enqueues everything up to the gradients (forward, criterion,
@@ -346,7 +349,7 @@ typedef struct gsx_step {
     float* loss;                   /* 3 floats: [0] the criterion; GSX_LOSS_L1_SSIM also writes [1] = L1, [2] = SSIM */
     void* loss_ws; size_t loss_ws_bytes;   /* gsx_image_loss_workspace_bytes() or gsx_l1_ssim_workspace_bytes(3, H, W) */
     void* adam_ws; size_t adam_ws_bytes;   /* gsx_clip_adam_workspace_bytes() (+ 8 * ceil(N / 256), see above) */
-    int64_t* counts_pinned_host;   /* 2 x i64 of pinned host memory: D, mismatch count */
+    int64_t* counts_pinned_host;   /* 4 x i64 of pinned host memory: D, mismatch count, 1 + number of empty tiles (0: not known), spare */
     void* count_event;             /* hipEvent_t */
 } gsx_step;
 int gsx_train_step(const gsx_step* s, void* stream);
