@@ -343,6 +343,52 @@ def test_fused_train_step_equals_modular_step(loss_name):
     assert float(runs[True][0][-1][0]) != float(runs[True][0][0][0])     # the losses are per step, not one buffer seen five times
 
 
+@pytest.mark.parametrize("fixture", ["exit3_n800_40x40", "exitop0_n500_32x32", "exit11_n1600_64x48"])
+def test_fused_step_global_exit_equals_modular_step(fixture):
+    """The one-call step enqueues the global-exit path only when the tile sort reports no empty tile (gsx.h, gsx_train_step): on the
+    reference-run exit fixtures (every tile covered, the exit fires) it must run it and composite the reference's count; with the
+    splats pushed off one corner (an empty tile: the exit cannot fire) it leaves the three launches out -- either way loss,
+    gradients and exit count equal the modular step's, which always enqueues the path."""
+    from helpers import load_golden
+    from gaussian_splatting_amd import GaussianSplat, trainer as T, render as R
+    dev = torch.device("cuda:0")
+    fx = load_golden(fixture)
+    H, W = fx["H"], fx["W"]
+    n = fx["params"]["positions"].shape[0]
+    pose = torch.from_numpy(fx["poses"][0])[None].to(dev)
+    target = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    for shove in (False, True):
+        out = {}
+        for fused in (False, True):
+            m = GaussianSplat(n)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in fx["params"].items()})
+            m = m.to(dev)
+            opt = T.make_optimizer(m, fused_clip_norm=0.1)
+            T.FUSED_STEP = fused
+            try:
+                first = None
+                if shove:      # run once as is to learn where the splats land, then move every mean that lands in tile (0, 0) out of the image
+                    with torch.no_grad():
+                        o = m(pose, (H, W))
+                        p2 = o["positions"][0]
+                        px = (p2[:, 0] + 1) * (W - 1) / 2; py = (p2[:, 1] + 1) * (H - 1) / 2
+                        m.scales.mul_(1.0e-3)                                # pin-point footprints: tile (0, 0) stays empty for sure
+                        near = (px < 40) & (py < 40)
+                        m.positions[near, 0] += 1.0e3
+                loss = T.train_step(m, opt, pose, target, T.l1_loss, 0.1)
+                out[fused] = (loss.clone(), [p.grad.clone() for p in m.parameters()], m.last_n_composited(), [p.detach().clone() for p in m.parameters()])
+                assert (getattr(opt, "_fused_step", None) is not None) == fused
+            finally:
+                T.FUSED_STEP = True
+        a, b = out[False], out[True]
+        assert a[2] == b[2], (fixture, shove, a[2], b[2])
+        if not shove:
+            assert a[2][0] == int(fx["n_composited"]) < n, "the exit fires on the fixture as the reference ran it"
+        else:
+            assert a[2][0] == n, "an empty tile: no exit"
+        assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+
+
 def test_fused_train_step_declines_what_it_cannot_do():
     """Anything but the plain case stays on the modular path: a wrapped model, a torch optimizer, a custom loss, B > 1,
     another clip norm, a depth map."""
