@@ -13,8 +13,9 @@
  *     nothing here allocates or frees device memory.
  *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous.  Three entry points make the HOST
  *     wait: gsx_bin_instances synchronises the stream once (8-byte read-back of the instance count); gsx_train_step and
- *     gsx_train_step_grads block on the caller's count_event (recorded in the middle of the view's forward: the host
- *     learns the instance count while the GPU composites) before they enqueue the backward; the gsx_comm_* calls are
+ *     gsx_train_step_grads block on the caller's count_event (recorded in the middle of the view's forward, behind the
+ *     tile sort: the host learns the instance count and the number of empty tiles while the GPU composites) before they
+ *     enqueue the criterion and the backward; the gsx_comm_* calls are
  *     RCCL's and block as RCCL does (gsx_comm_init until every rank has joined).
  *   - fp32 arithmetic; integer products (sort keys, tile rectangles, tile ranges) are bit-exact
  *     against oracle/gsx_oracle.c.
