@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float w = ldexpf(m[k], e[k]) * al;
                     C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float w = ldexpf(m[k], e[k]) * al;
                     C0[k] += w * b.z; C1[k] += w * b.w; C2[k] += w * c.x;
@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                     const float4 a = s_a[j], b = s_b[j];
                     const float dx = gx - a.x, dy = gy - a.y;
-                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float am = b.y * __builtin_amdgcn_exp2f(q);
                     A = A + (1.0f - A) * am;
                     if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             for (int k = 0; k < 4; k++) {
                 if ((k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3) & bit) {      // one scalar test per quadrant
                     const float dx = gx[k & 1] - a.x, dy = gy[k >> 1] - a.y;
-                                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                     const float al = b.y * __builtin_amdgcn_exp2f(q);
                     const float f = one_minus(al);
                     m[k] *= __builtin_amdgcn_rcpf(f);                 // T_k = T_{k+1} / (1 - alpha_k)
