@@ -1321,7 +1321,11 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // the end in ONE workgroup (17 k splats, 1.4 ms on the bench scene after 1200 steps: the trainer step had doubled), while
         // a sparse tile at the image's edge answers in microseconds.  Everybody still arrives at the barrier below.
         bool quit = false;
-        for (int tile = blockIdx.x; tile < n_tiles && !quit; tile += n_blocks) {
+        for (int ti = blockIdx.x; ti < n_tiles && !quit; ti += n_blocks) {
+            // (a stride walk over the tiles: with the identity map the first tiles of all workgroups are the image's top rows -- on
+            // the bench orbit the dense band itself, so that the first sparse tile, the one with the pixel that never saturates,
+            // only came up in the second round of tiles, 60 us into the search)
+            const int tile = (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles);
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
             const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
             const bool inside = x < W && y < H;
@@ -1381,11 +1385,17 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             return;
         }
         if (threadIdx.x == 0) {
-            atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
-            // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
-            __hip_atomic_fetch_add(state + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t target = round * n_blocks;
-            while (__hip_atomic_load(state + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+            // A workgroup that has seen (or raised) "never" neither adds to the maximum nor arrives: the search is over, and whoever
+            // waits at the barrier leaves it on the same word.  (512 arrivals + 512 maxima on one cache line are ~65 us of
+            // serialised atomics -- what was left of the search on a trained bench scene once the walks ended early.)
+            if (!quit) {
+                atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+                // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
+                __hip_atomic_fetch_add(state + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t target = round * n_blocks;
+                while (__hip_atomic_load(state + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                       __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != GSX_RANK_NONE) __builtin_amdgcn_s_sleep(8);
+            }
             s_k = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
