@@ -21,6 +21,7 @@
 // backward); HBM traffic per instance is 52 B forward + 24 B of chunk state.  No MFMA: there is no
 // contraction on this path.
 #include "gsx_common.h"
+#include <type_traits>
 
 namespace gsx {
 
@@ -613,7 +614,9 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 }
 
 constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (written by the last list block of the chunk pass)
+constexpr int kWorkBig = 6;               // work[6]: how many of them have more than kParSmall chunks (they come first in the list)
 constexpr int kListTiles = 16;            // tiles per list block
+constexpr int kParSmall = 12;             // = ParShape::U: a tile of up to this many chunks is one GROUP's work in the combine pass
 
 // The tiles that hold something, as a list (order_tab's room: a shallow view has no level-order table), so that the combine pass
 // runs on those alone: the bench scene leaves 3600-3900 of its 4096 tiles empty, and a grid with one workgroup per
@@ -622,31 +625,50 @@ constexpr int kListTiles = 16;            // tiles per list block
 // Runs as the LAST blocks of the chunk pass's grid (a launch of its own until late in round 3: 6.4 us of launch floor), beside the
 // pass's tail.  No atomics: a block counts the non-empty tiles in front of its own from the chunk table (n_tiles words out of the
 // L2), so the list is in tile order and the same from run to run; the block that holds the last tile writes the count.
-__device__ __forceinline__ void tile_list_block(int lb, uint32_t* s_scratch /* >= 5 words */,
+__device__ __forceinline__ void tile_list_block(int lb, uint32_t* s_scratch /* >= 13 words */,
     const uint32_t* __restrict__ chunk_base, int H, int W, int tw, int n_tiles,
     uint32_t* __restrict__ work, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha, float* __restrict__ depth_map)
 {
+    // Two parts: first the tiles of more than kParSmall chunks (the combine pass gives each a workgroup), then the small ones (four
+    // to a workgroup, one per group of 256 threads).  A block needs the number of big tiles in front of its own, of small ones in
+    // front of its own, and of big ones altogether.
     const int t0 = lb * kListTiles;
-    uint32_t before = 0;
-    for (int t = (int)threadIdx.x; t < t0; t += kBlock) before += (chunk_base[t + 1] > chunk_base[t]) ? 1u : 0u;
+    uint32_t big_before = 0, small_before = 0, big_all = 0;
+    for (int t = (int)threadIdx.x; t < n_tiles; t += kBlock) {
+        const uint32_t nc = chunk_base[t + 1] - chunk_base[t];
+        const uint32_t big = nc > (uint32_t)kParSmall ? 1u : 0u;
+        big_all += big;
+        if (t < t0) { big_before += big; small_before += (nc != 0u && !big) ? 1u : 0u; }
+    }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_down((int)before, d, 64);
-    if ((threadIdx.x & 63u) == 0u) s_scratch[threadIdx.x >> 6] = before;
+    for (int d = 32; d > 0; d >>= 1) {
+        big_before += (uint32_t)__shfl_down((int)big_before, d, 64);
+        small_before += (uint32_t)__shfl_down((int)small_before, d, 64);
+        big_all += (uint32_t)__shfl_down((int)big_all, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_scratch[threadIdx.x >> 6] = big_before; s_scratch[4 + (threadIdx.x >> 6)] = small_before; s_scratch[8 + (threadIdx.x >> 6)] = big_all;
+    }
     __syncthreads();
-    const uint32_t base = (s_scratch[0] + s_scratch[1]) + (s_scratch[2] + s_scratch[3]);
+    const uint32_t n_big = (s_scratch[8] + s_scratch[9]) + (s_scratch[10] + s_scratch[11]);
+    const uint32_t base_big = (s_scratch[0] + s_scratch[1]) + (s_scratch[2] + s_scratch[3]);
+    const uint32_t base_small = n_big + ((s_scratch[4] + s_scratch[5]) + (s_scratch[6] + s_scratch[7]));
     if (threadIdx.x < 64u) {
         const int t = t0 + (int)threadIdx.x;
         const bool valid = threadIdx.x < (uint32_t)kListTiles && t < n_tiles;
-        const bool holds = valid && chunk_base[t + 1] > chunk_base[t];
-        const unsigned long long mh = __builtin_amdgcn_ballot_w64(holds), me = __builtin_amdgcn_ballot_w64(valid && !holds);
-        if (holds) list[base + (uint32_t)__popcll(mh & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)t;
+        const uint32_t nc = valid ? chunk_base[t + 1] - chunk_base[t] : 0u;
+        const bool big = nc > (uint32_t)kParSmall, small = nc != 0u && !big;
+        const unsigned long long mb = __builtin_amdgcn_ballot_w64(big), ms = __builtin_amdgcn_ballot_w64(small);
+        const unsigned long long me = __builtin_amdgcn_ballot_w64(valid && nc == 0u), lt = (1ull << threadIdx.x) - 1ull;
+        if (big) list[base_big + (uint32_t)__popcll(mb & lt)] = (uint32_t)t;
+        if (small) list[base_small + (uint32_t)__popcll(ms & lt)] = (uint32_t)t;
         if (threadIdx.x == 0u) {
-            s_scratch[4] = (uint32_t)me;
-            if (t0 + kListTiles >= n_tiles) work[kWorkNonEmpty] = base + (uint32_t)__popcll(mh);
+            s_scratch[12] = (uint32_t)me;
+            if (t0 + kListTiles >= n_tiles) { work[kWorkNonEmpty] = base_small + (uint32_t)__popcll(ms); work[kWorkBig] = n_big; }
         }
     }
     __syncthreads();
-    uint32_t em = s_scratch[4];       // (the veto of the empty tiles: tile_combine_par_kernel, from the count)
+    uint32_t em = s_scratch[12];      // (the veto of the empty tiles: tile_combine_par_kernel, from the count)
     const size_t P = (size_t)H * W;
     while (em) {
         const int tile = t0 + __builtin_ctz(em);
@@ -693,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     __shared__ float s_growth[4];
     if (blockIdx.x == 0) {                    // the combine pass (next launch) counts in these; the chunk pass itself reads neither
         if (threadIdx.x < 4) state[threadIdx.x] = 0u;
-        if (threadIdx.x < 16 && threadIdx.x != (uint32_t)kWorkNonEmpty) work[threadIdx.x] = 0u;      // (work[5]: the last list block's)
+        if (threadIdx.x < 16 && threadIdx.x != (uint32_t)kWorkNonEmpty && threadIdx.x != (uint32_t)kWorkBig) work[threadIdx.x] = 0u;   // (work[5], [6]: the last list block's)
     }
     const uint32_t n_chunks = chunk_base[n_tiles];
     if (n_chunks >= kDeepChunks) return;                                // a deep view is the other kernel's (uniform over the workgroup)
@@ -1045,7 +1067,11 @@ __global__ __launch_bounds__(kBlock) void tile_combine_kernel(
 // (tools/tile_depth_stats.py), so the kernel above was ~300 workgroups walking three or four dependent batches each --
 // 40 us of memory round trips for the forward scan alone (ablation: tools/ab_kstats.sh) with the chip empty.  Here such a tile
 // is ONE batch: one round trip for the states, one barrier, one reservation in the work lists.
-// Tiles of more than 64 chunks loop (forward, then backward with the states reloaded, as above).
+// Tiles of more than 48 chunks loop (forward, then backward with the states reloaded, as above).
+// A tile of at most U = 12 chunks is one group's work, and a workgroup takes FOUR of them side by side (the list's second part:
+// tile_list_block).  After a thousand trainer steps the bench scene has splats on all 4096 tiles, 3700 of them with one or two
+// chunks: one tile per workgroup and iteration was 8 dependent iterations per workgroup with three groups idle (97 us); four
+// at a time it is 47 us, and the bench scene's own 300 deep tiles are untouched (tools/soak_ktrace.sh).
 // ------------------------------------------------------------------------------------------
 // four groups of 256 threads, 12 chunks per group and batch: what 128 registers hold without scratch (with the depth map's
 // sixth word 9 registers go to scratch; the two instantiations must cut the list alike, or the image would depend in its
@@ -1063,6 +1089,7 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
 {
     constexpr int G = kParGroups, U = ParShape<DEPTH>::U, kParBatch = ParShape<DEPTH>::Batch, NA = DEPTH ? 6 : 5;
     static_assert(kParBatch <= 64 && G * kBlock <= 1024, "one wave builds a batch's work-list entries, lane = chunk");
+    static_assert(U == kParSmall, "the list's second part holds the tiles that fit one group");
     // per group and pixel: what the group's chunks add (colour 3, depth with DEPTH) and let through (mantissa, exponent)
     __shared__ float s_agg[G][NA][kPixPerTile];
     __shared__ uint8_t s_dark[kParBatch][4];
@@ -1073,12 +1100,18 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     // (and says "no exit rank" itself: the search behind this launch would, but the one-call trainer step does not even enqueue it
     // when the host knows of an empty tile -- gsx_view.hip)
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_held < (uint32_t)n_tiles) { atomicOr(state + 1, 1u); state[0] = GSX_RANK_NONE; }
-    for (uint32_t item = blockIdx.x; item < n_held; item += gridDim.x) {
-    const int tile = (int)list[item];
-    const uint32_t c0 = chunk_base[tile], c1 = chunk_base[tile + 1];
+    const uint32_t n_big = min(work[kWorkBig], n_held);
+    // One tile.  SOLO: the tile is this GROUP's alone (up to U chunks: one batch, nothing to exchange), four tiles to the workgroup;
+    // `slot0` is the list position of group 0's tile, `valid` false for a group past the list's end (it still meets every barrier).
+    // The same operations in the same order as a tile that has the four groups to itself and chunks for the first only: the same bits.
+    auto one_tile = [&](auto solo_c, const int tile, const bool valid, const uint32_t slot0) {
+    constexpr bool SOLO = decltype(solo_c)::value;
+    const uint32_t c0 = valid ? chunk_base[tile] : 0u, c1 = valid ? chunk_base[tile + 1] : 0u;
     // (group and quadrant are wave-uniform: in scalar registers, so that a chunk's address is a scalar base + the pixel's offset)
     const int pix = threadIdx.x & (kPixPerTile - 1);
-    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), quad = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 3u));
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int grp_at = SOLO ? 0 : grp;                                // where in a batch the group's chunks stand
+    const int quad = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 3u));
     const uint32_t lane = threadIdx.x & 63u;
     int x, y; pix_xy(quad, pix & 63, tile % tw, tile / tw, x, y);
     const bool inside = x < W && y < H;
@@ -1090,7 +1123,7 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     float l0[U], l1[U], l2[U], l3[U], l4[U];
     uint32_t sb_last = c0;
     // work-list reservation of the last batch (wave 0), emitted after the backward scan
-    int wl_cls = -1; bool wl_halves = false; uint32_t wl_base = 0u, wl_below = 0u;
+    int wl_cls = -1; bool wl_halves = false; uint32_t wl_base = 0u, wl_below = 0u, wl_chunk = 0u;
     const uint32_t ch = chunk_base[n_tiles + 1];
 
     // the states of this group's chunks [g0, g0 + U) (clamped: a group past the list's end loads nothing)
@@ -1098,6 +1131,7 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
         if (g0 < c1) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                if (SOLO && g0 + u >= c1) break;                  // (uniform over the wave; a small tile is mostly one or two chunks)
                 const uint32_t c = min(g0 + u, c1 - 1u);
                 l0[u] = *state_ptr(chunk_state, c, 0, pix); l1[u] = *state_ptr(chunk_state, c, 1, pix);
                 l2[u] = *state_ptr(chunk_state, c, 2, pix); l3[u] = *state_ptr(chunk_state, c, 3, pix);
@@ -1105,9 +1139,9 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
             }
         }
     };
-    // ... folded into one and published (identity for a group past the end)
-    auto publish = [&](uint32_t g0, const float* l5) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, am = 1.f; int ae = 0;
+    // ... folded into one (identity for a group past the end)
+    auto fold = [&](uint32_t g0, const float* l5, float& a0, float& a1, float& a2, float& ad, float& am, int& ae) {
+        a0 = 0.f; a1 = 0.f; a2 = 0.f; ad = 0.f; am = 1.f; ae = 0;
         if (g0 < c1) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -1121,6 +1155,11 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
                 }
             }
         }
+    };
+    // ... and published
+    auto publish = [&](uint32_t g0, const float* l5) {
+        float a0, a1, a2, ad, am; int ae;
+        fold(g0, l5, a0, a1, a2, ad, am, ae);
         s_agg[grp][0][pix] = a0; s_agg[grp][1][pix] = a1; s_agg[grp][2][pix] = a2;
         if (DEPTH) s_agg[grp][3][pix] = ad;
         s_agg[grp][NA - 2][pix] = am; s_agg[grp][NA - 1][pix] = __int_as_float(ae);
@@ -1158,24 +1197,29 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
         }
     };
 
-    for (uint32_t sb = c0; sb < c1; sb += kParBatch) {
+    for (uint32_t sb = c0; SOLO ? sb == c0 : sb < c1; sb += kParBatch) {
         sb_last = sb;
-        const uint32_t g0 = sb + (uint32_t)grp * U;
+        const uint32_t g0 = sb + (uint32_t)grp_at * U;
         uint32_t meta_l = 0u;                 // lane u: chunk g0 + u's flag word
         float l5[DEPTH ? U : 1];
         if (g0 < c1) {
             if (lane < (uint32_t)U) meta_l = chunk_meta[min(g0 + lane, c1 - 1u)];
             if (DEPTH) {
 #pragma unroll
-                for (int u = 0; u < U; u++) l5[u] = *state_ptr(chunk_state, min(g0 + u, c1 - 1u), 5, pix);
+                for (int u = 0; u < U; u++) {
+                    if (SOLO && g0 + u >= c1) break;
+                    l5[u] = *state_ptr(chunk_state, min(g0 + u, c1 - 1u), 5, pix);
+                }
             }
         }
         load_states(g0);
-        publish(g0, l5);
         nonmono = nonmono || __builtin_amdgcn_ballot_w64((meta_l & kMetaNonMono) != 0u) != 0ull;
-        __syncthreads();
         // what stands in front of this group (pm, pe); the state behind the whole batch
         float pm = 1.f; int pe = 0;
+        if constexpr (SOLO) fold(g0, l5, C0, C1, C2, Dm, m, e);
+        else {
+        publish(g0, l5);
+        __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (g == grp) { pm = m; pe = e; }
@@ -1186,10 +1230,12 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
             e += __float_as_int(s_agg[g][NA - 1][pix]);
             renorm(m, e);
         }
+        }
         if (need_bwd && g0 < c1) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t c = g0 + u;
+                if (SOLO && c >= c1) break;
                 if (c < c1) {
                     // occlusion cut (see the kernel above): quadrant `quad` of chunk c is dark when every pixel enters with
                     // |T| < 2^-(cut + growth bits of c)
@@ -1210,14 +1256,21 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
         __syncthreads();                      // s_dark is complete; s_agg may be rewritten
         if (need_bwd && threadIdx.x < 64u) {
             // Work lists of the backward by expected cost (see the kernel above), lane = chunk: one reservation per class per batch
-            const uint32_t c = sb + lane;
+            // (SOLO: lanes [g * U, g * U + U) are the chunks of group g's tile)
+            uint32_t c = sb + lane, wc0 = c0, wc1 = c1; int wtile = tile;
+            if constexpr (SOLO) {
+                const uint32_t g = lane / (uint32_t)U, slot = slot0 + g;
+                wc0 = wc1 = 0u;
+                if (g < (uint32_t)G && slot < n_held) { wtile = (int)list[slot]; wc0 = chunk_base[wtile]; wc1 = chunk_base[wtile + 1]; }
+                c = wc0 + (lane - g * (uint32_t)U);
+            }
             int cls = -1; bool halves = false;
-            if (c < c1 && lane < (uint32_t)kParBatch) {
+            if (c < wc1 && lane < (uint32_t)kParBatch) {
                 const uint32_t meta = chunk_meta[c];
                 const uint32_t n_dark = (uint32_t)(s_dark[lane][0] + s_dark[lane][1] + s_dark[lane][2] + s_dark[lane][3]);
                 uint32_t est = ((meta >> GSX_META_COST_SHIFT) & GSX_META_COST_MASK) * (4u - n_dark);
                 if (ch >= 128u && n_dark != 4u) {
-                    const uint32_t len = (c + 1u < c1) ? ch : (ranges[2 * tile + 1] - ranges[2 * tile]) - (c - c0) * ch;
+                    const uint32_t len = (c + 1u < wc1) ? ch : (ranges[2 * wtile + 1] - ranges[2 * wtile]) - (c - wc0) * ch;
                     halves = len > (ch >> 1);
                 }
                 if (halves) { est >>= 1; cls = est >= 5u * ch ? 0 : est >= 3u * ch ? 1 : est >= 3u * (ch >> 1) ? 2 : 3; }
@@ -1234,12 +1287,12 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
             }
             uint32_t base = 0u;
             if (lane < (uint32_t)kWorkClasses && mine) base = atomicAdd(work_counters(work, false) + lane, mine);
-            wl_cls = cls; wl_halves = halves; wl_base = base; wl_below = below;
-            if (sb + kParBatch < c1) list_emit(c);          // (the last batch's round trip runs under the backward scan)
+            wl_cls = cls; wl_halves = halves; wl_base = base; wl_below = below; wl_chunk = c;
+            if (!SOLO && sb + kParBatch < c1) list_emit(c); // (the last batch's round trip runs under the backward scan)
         }
     }
     const float A = 1.0f - ldexpf(m, e);
-    if (grp == 0 && inside) {
+    if ((SOLO ? valid : grp == 0) && inside) {
         const size_t P = (size_t)H * W, p = (size_t)y * W + x;
         rgb[p] = C0; rgb[P + p] = C1; rgb[2*P + p] = C2;
         alpha[p] = A;
@@ -1247,13 +1300,20 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     }
     {
         // the veto of the global early exit and the non-monotone flag: as in the kernel above
-        const bool tile_nonmono = __syncthreads_or(nonmono) != 0;
-        const bool unsat = grp == 0 && inside && (A <= GSX_SAT_ALPHA - 1e-5f) && !tile_nonmono;
-        const uint32_t raise = (__syncthreads_or(unsat) ? 1u : 0u) | (tile_nonmono ? 2u : 0u);
+        // (SOLO: every wave of a group has read its tile's flag words, so `nonmono` is the tile's already)
+        const bool any_nonmono = __syncthreads_or(nonmono) != 0;
+        const bool tile_nonmono = SOLO ? nonmono : any_nonmono;
+        const bool unsat = (SOLO ? valid : grp == 0) && inside && (A <= GSX_SAT_ALPHA - 1e-5f) && !tile_nonmono;
+        const uint32_t raise = (__syncthreads_or(unsat) ? 1u : 0u) | (any_nonmono ? 2u : 0u);
         if (raise && threadIdx.x == 0 &&
             (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & raise) != raise) atomicOr(state + 1, raise);
     }
-    if (need_bwd && c1 > c0) {
+    if constexpr (SOLO) {
+        if (need_bwd) {
+            scan_back(c0, 0.f, 0.f, 0.f);                        // (nothing behind the tile's only batch; past-the-end groups: c0 = c1)
+            if (threadIdx.x < 64u) list_emit(wl_chunk);
+        }
+    } else if (need_bwd && c1 > c0) {
         // the last batch: states still in registers, the groups' results still in LDS
         float F0 = 0.f, F1 = 0.f, F2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
         behind(F0, F1, F2, b0, b1, b2);
@@ -1271,6 +1331,15 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
         }
     }
     __syncthreads();                          // the next tile rewrites s_agg and s_dark
+    };
+    // the big tiles, one at a time; then the small ones, four at a time
+    for (uint32_t item = blockIdx.x; item < n_big; item += gridDim.x)
+        one_tile(std::false_type{}, (int)list[item], true, 0u);
+    const int grp_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const uint32_t first_q = (blockIdx.x + gridDim.x - n_big % gridDim.x) % gridDim.x;      // (the first workgroup without a big tile takes the first four)
+    for (uint32_t slot0 = n_big + first_q * G; slot0 < n_held; slot0 += gridDim.x * G) {
+        const bool valid = slot0 + (uint32_t)grp_k < n_held;
+        one_tile(std::true_type{}, valid ? (int)list[slot0 + (uint32_t)grp_k] : 0, valid, slot0);
     }
 }
 
