@@ -212,6 +212,11 @@ constexpr int kPayBias = 65;                           // payload byte = q + 65 
 __device__ __host__ __forceinline__ size_t tail_hdr_offset(size_t max_chunks) { return 2 * max_chunks + 16 + 2 * (size_t)kWorkClasses * 2 * max_chunks; }
 // mid-chunk states of a shallow view: behind header, order table and payloads (gsx_constants.h)
 __device__ __host__ __forceinline__ size_t tail_mid_offset(size_t max_chunks) { return tail_hdr_offset(max_chunks) + 66 * max_chunks; }
+// quadrant masks of a shallow view's instances, one byte each, in the chunk's payload words (which only a deep view publishes
+// into): the chunk pass computes every instance's mask (quad_mask: ~370 instructions per batch of 64) and leaves it here, so
+// that the backward reads a byte instead of computing it again
+static_assert(GSX_CHUNK <= 64 * 4, "a chunk's masks fit its 64 payload words");
+__device__ __host__ __forceinline__ size_t tail_pay_offset(size_t max_chunks) { return tail_hdr_offset(max_chunks) + 2 * max_chunks; }
 __device__ __forceinline__ float* mid_ptr(float* mid_state, uint32_t chunk, int word, int pix)
 {
     return mid_state + ((size_t)chunk * GSX_MID_WORDS + word) * kPixPerTile + pix;
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     const uint32_t* __restrict__ chunk_base, int n_tiles, int H, int W, int tw, float stepx, float stepy,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
     float* __restrict__ mid_state, uint32_t n_list_blocks, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha,
-    float* __restrict__ depth_map)
+    float* __restrict__ depth_map, uint8_t* __restrict__ masks)
 {
     // C0 C1 C2 m e (Dm).  Without a depth map the parts are 20 KB instead of 24: seven workgroups per CU instead of six, i.e.
     // seven waves per SIMD (65 VGPRs), and the chunk pass of the bench scene 195 -> 189 us with the combine pass
@@ -759,6 +764,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
             const float4 c = R[2];
             my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE);
             s_a[lane] = a; s_b[lane] = b; s_c[lane] = c;
+            if (masks) masks[(size_t)chunk * (64 * 4) + (i - g.begin)] = (uint8_t)my_mask;          // for the backward
         }
         const unsigned long long q0 = __builtin_amdgcn_ballot_w64((my_mask & 1u) != 0u), q1 = __builtin_amdgcn_ballot_w64((my_mask & 2u) != 0u);
         const unsigned long long q2 = __builtin_amdgcn_ballot_w64((my_mask & 4u) != 0u), q3 = __builtin_amdgcn_ballot_w64((my_mask & 8u) != 0u);
@@ -1522,7 +1528,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
     const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed,
-    uint32_t max_chunks, const float* __restrict__ mid_state)
+    uint32_t max_chunks, const float* __restrict__ mid_state, const uint8_t* __restrict__ masks)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch];
     __shared__ float s_cx[kCBatch];
@@ -1543,6 +1549,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const uint32_t item = work_list(const_cast<uint32_t*>(work), after_exit, cls, max_chunks)[b];
     const uint32_t chunk = item & kItemChunk;
     ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    // a shallow view's chunk pass left every instance's quadrant mask (tail_pay_offset)
+    const uint8_t* chunk_masks = (chunk_base[n_tiles] < kDeepChunks) ? masks + (size_t)chunk * (64 * 4) - g.begin : nullptr;
     // a chunk in two halves (shallow views: the combine pass made two entries of it): this wave walks one of them
     const bool front = (item & kItemFront) != 0u;
     if (item & (kItemFront | kItemBack)) {
@@ -1648,7 +1656,8 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
             const int ty0 = (int)(by & 0xffff) >> GSX_TILE_SHIFT;
             s_slot[lane] = offsets[r] + (uint32_t)((g.ty - ty0) * (tx1 - tx0) + (g.tx - tx0));
             const float4 a = R[0], b = R[1];
-            my_mask = quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE) & ~dark_mask;
+            my_mask = (chunk_masks ? (uint32_t)chunk_masks[bs + lane]
+                                   : quad_mask(a, b, c.z, c.w, qx, qy, QE, GSX_CUT_LOG2_FOR(H, W), GSX_CUT_MIN_EXP_FOR(H, W), H < GSX_TILE || W < GSX_TILE)) & ~dark_mask;
             s_a[lane] = a; s_b[lane] = b; s_cx[lane] = c.x;
         }
         // The batch's quadrant masks as four wave-uniform bit sets (bit j of qk: instance j reaches quadrant k, dark quadrants
@@ -1776,12 +1785,12 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map);
+        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<true><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
-        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr);
+        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
@@ -1828,7 +1837,8 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     chunk_bwd_kernel<<<dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state, meta, meta + max_chunks, meta + 2 * (size_t)max_chunks,
-        d_rgb, partials, prezeroed, (uint32_t)max_chunks, reinterpret_cast<const float*>(meta + tail_mid_offset((size_t)max_chunks)));
+        d_rgb, partials, prezeroed, (uint32_t)max_chunks, reinterpret_cast<const float*>(meta + tail_mid_offset((size_t)max_chunks)),
+        reinterpret_cast<const uint8_t*>(meta + tail_pay_offset((size_t)max_chunks)));
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
