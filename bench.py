@@ -213,6 +213,11 @@ def main():
 
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    # stdout carries ONE line, the JSON: whatever a native library writes to file descriptor 1 on the way (RCCL prints a version banner
+    # there when its first communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.hang_dump == 0 and args.gpus > 1:
         args.hang_dump = 900                         # multi-rank default: a hang leaves a stack trace instead of silence
     if args.hang_dump > 0:                           # a rank stuck in a collective prints where, then exits non-zero
@@ -436,7 +441,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "rccl": rccl, "stage_ms": stages,
             "inference_orbit": inference,
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if use_dp:
         dist.destroy_process_group()
 
