@@ -165,6 +165,19 @@ __device__ __forceinline__ ChunkGeom chunk_locate(const uint32_t* __restrict__ c
     return g;
 }
 
+// the same with the tile known (a shallow view's chunk pass leaves it in the chunk's header word, which only a deep view
+// publishes into): two round trips instead of the search's twelve at the start of every wave of the backward
+__device__ __forceinline__ ChunkGeom chunk_locate_in(const uint32_t* __restrict__ chunk_base, int n_tiles, uint32_t chunk,
+                                                     const uint32_t* __restrict__ ranges, int tw, int tile)
+{
+    const uint32_t ch = chunk_base[n_tiles + 1];
+    ChunkGeom g;
+    g.tile = tile; g.tx = tile % tw; g.ty = tile / tw;
+    g.begin = ranges[2*tile] + (chunk - chunk_base[tile]) * ch;
+    g.end = min(g.begin + ch, ranges[2*tile+1]);
+    return g;
+}
+
 // pixel p of a tile in "quadrant-major" order: k = p >> 6 picks the 8x8 quadrant, lane = p & 63
 __device__ __forceinline__ void pix_xy(int k, int lane, int tx, int ty, int& x, int& y)
 {
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
     const uint32_t* __restrict__ chunk_base, int n_tiles, int H, int W, int tw, float stepx, float stepy,
     uint32_t* __restrict__ state, float* __restrict__ chunk_state, uint32_t* __restrict__ chunk_meta, uint32_t* __restrict__ work,
     float* __restrict__ mid_state, uint32_t n_list_blocks, uint32_t* __restrict__ list, float* __restrict__ rgb, float* __restrict__ alpha,
-    float* __restrict__ depth_map, uint8_t* __restrict__ masks)
+    float* __restrict__ depth_map, uint8_t* __restrict__ masks, uint32_t* __restrict__ chunk_tile)
 {
     // C0 C1 C2 m e (Dm).  Without a depth map the parts are 20 KB instead of 24: seven workgroups per CU instead of six, i.e.
     // seven waves per SIMD (65 VGPRs), and the chunk pass of the bench scene 195 -> 189 us with the combine pass
@@ -845,6 +858,7 @@ __global__ __launch_bounds__(kBlock) void chunk_fwd_wg_kernel(
         // whole bits, rounded up, + 1 of slack for the rounding of the sum; GSX_META_GROWTH_MAX = "unbounded" (no cut)
         const uint32_t gbits = (gsum == 0.0f) ? 0u : (gsum < (float)(GSX_META_GROWTH_MAX - 2)) ? (uint32_t)gsum + 2u : (uint32_t)GSX_META_GROWTH_MAX;
         chunk_meta[chunk] = (gbits << GSX_META_GROWTH_SHIFT) | (csum << GSX_META_COST_SHIFT) | (nm ? kMetaNonMono : 0u);
+        if (chunk_tile) chunk_tile[chunk] = (uint32_t)g.tile;             // for the backward (chunk_locate_in)
     }
 }
 
@@ -1528,7 +1542,7 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
     const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed,
-    uint32_t max_chunks, const float* __restrict__ mid_state, const uint8_t* __restrict__ masks)
+    uint32_t max_chunks, const float* __restrict__ mid_state, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ chunk_tile)
 {
     __shared__ float4 s_a[kCBatch], s_b[kCBatch];
     __shared__ float s_cx[kCBatch];
@@ -1548,9 +1562,11 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     if (cls == kWorkClasses) return;
     const uint32_t item = work_list(const_cast<uint32_t*>(work), after_exit, cls, max_chunks)[b];
     const uint32_t chunk = item & kItemChunk;
-    ChunkGeom g = chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
-    // a shallow view's chunk pass left every instance's quadrant mask (tail_pay_offset)
-    const uint8_t* chunk_masks = (chunk_base[n_tiles] < kDeepChunks) ? masks + (size_t)chunk * (64 * 4) - g.begin : nullptr;
+    // a shallow view's chunk pass left the chunk's tile (header word) and every instance's quadrant mask (payload words)
+    const bool shallow = chunk_base[n_tiles] < kDeepChunks;
+    ChunkGeom g = shallow ? chunk_locate_in(chunk_base, n_tiles, chunk, ranges, tw, (int)chunk_tile[chunk])
+                                                  : chunk_locate(chunk_base, n_tiles, chunk, ranges, tw);
+    const uint8_t* chunk_masks = shallow ? masks + (size_t)chunk * (64 * 4) - g.begin : nullptr;
     // a chunk in two halves (shallow views: the combine pass made two entries of it): this wave walks one of them
     const bool front = (item & kItemFront) != 0u;
     if (item & (kItemFront | kItemBack)) {
@@ -1785,12 +1801,12 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr);
+        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr, need_bwd ? hdr : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<true><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
-        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr);
+        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr, need_bwd ? hdr : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
@@ -1838,7 +1854,7 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state, meta, meta + max_chunks, meta + 2 * (size_t)max_chunks,
         d_rgb, partials, prezeroed, (uint32_t)max_chunks, reinterpret_cast<const float*>(meta + tail_mid_offset((size_t)max_chunks)),
-        reinterpret_cast<const uint8_t*>(meta + tail_pay_offset((size_t)max_chunks)));
+        reinterpret_cast<const uint8_t*>(meta + tail_pay_offset((size_t)max_chunks)), meta + tail_hdr_offset((size_t)max_chunks));
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

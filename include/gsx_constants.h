@@ -86,7 +86,7 @@
 /* Behind the work lists: what the chunk pass PUBLISHES per chunk when it is done -- a header word (the chunk's bound on the
  * growth of |T| in quarter-bits, or "unbounded") and 64 payload words (per pixel, one byte: floor(-4 log2 |T_local|) + 65) --
  * and the level-order dispatch table of the chunk pass (gsx_composite.hip, "Forward occlusion skipping").  A SHALLOW view
- * publishes nothing; its chunk pass keeps every instance's quadrant mask in the payload words instead (one byte per instance of
+ * publishes nothing; its chunk pass keeps the chunk's tile index in the header word and every instance's quadrant mask in the payload words instead (one byte per instance of
  * the chunk, in list order: bit w = the splat can reach 8x8 quadrant w), for the backward to read rather than compute again.
  * Behind those: the MID-CHUNK states of a shallow view (fewer than GSX_DEEP_CHUNKS chunks; round 3): per chunk and pixel
  * GSX_MID_WORDS floats -- local colour (3) and local transmittance (mantissa, exponent) of the chunk's SECOND half -- from
