@@ -16,10 +16,17 @@ size_t sort_ws_bytes_internal(int64_t n);
 // out that the buffers were too small when it reads the instance count, and retries).  A splat that covers more than
 // kEmitSolo tiles is written by its whole wavefront (lane l takes tiles l, l+64, ...): one screen-sized splat would
 // otherwise keep a single lane busy for thousands of iterations while the rest of the chip waits.
+// SCAN (the view driver): the exclusive scan of tiles_touched happens here instead of in a launch of its own (gsx_bin_count) -- a
+// rank's tile count IS the area of its box, gsx_build_records left the sums per kBlock ranks (`sums`), so a workgroup adds up the
+// sums in front of it (as scan_apply_kernel does) and scans its own 256 counts; it writes offsets_out[] for the backward, and the
+// last workgroup the total (and its mirror in pinned host memory, with the word behind it: gsx_bin_count).
 constexpr int kEmitSolo = 32;
+template <bool SCAN>
 __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ tile_box,
                                                       const uint32_t* __restrict__ offsets, int N, int tw,
-                                                      uint32_t capacity, uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks)
+                                                      uint32_t capacity, uint32_t* __restrict__ tiles, uint32_t* __restrict__ ranks,
+                                                      const uint64_t* __restrict__ sums, uint32_t* __restrict__ offsets_out,
+                                                      uint64_t* __restrict__ total, uint64_t* __restrict__ mirror)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -28,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ 
         if (tile_box) {                               // packed footprint in tile units (gsx_build_records): 4 B per rank, coalesced
             const uint32_t tb = tile_box[r];
             const int a = tb & 0xff, b = (tb >> 8) & 0xff, c = (tb >> 16) & 0xff, d = tb >> 24;
-            if (a <= c) { x0 = a; x1 = c + 1; y0 = b; y1 = d + 1; o = offsets[r]; }
+            if (a <= c) { x0 = a; x1 = c + 1; y0 = b; y1 = d + 1; if (!SCAN) o = offsets[r]; }
         } else {
             const float2 bb = *reinterpret_cast<const float2*>(rec + (size_t)GSX_REC_FLOATS * r + 10);
             const uint32_t bx = __float_as_uint(bb.x), by = __float_as_uint(bb.y);
@@ -36,11 +43,29 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const float* __restrict__ 
             if (xlo <= xhi) {
                 x0 = xlo >> GSX_TILE_SHIFT; x1 = (xhi >> GSX_TILE_SHIFT) + 1;
                 y0 = ylo >> GSX_TILE_SHIFT; y1 = (yhi >> GSX_TILE_SHIFT) + 1;
-                o = offsets[r];
+                if (!SCAN) o = offsets[r];
             }
         }
     }
     const int cnt = (x1 - x0) * (y1 - y0);
+    if (SCAN) {
+        __shared__ uint32_t s_wave[4];
+        __shared__ uint64_t s_pre[4];
+        uint64_t acc = 0;
+        for (int j = threadIdx.x; j < (int)blockIdx.x; j += kBlock) acc += sums[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        if (lane == 0) s_pre[threadIdx.x >> 6] = acc;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32((uint32_t)cnt, s_wave, &tot);      // barriers inside: s_pre is visible after it
+        const uint64_t pre = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+        o = (uint32_t)pre + ex;
+        if (r < N) offsets_out[r] = o;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+            total[0] = pre + (uint64_t)tot;
+            if (mirror) { mirror[0] = pre + (uint64_t)tot; mirror[1] = total[1]; }
+        }
+    }
     if (cnt > 0 && cnt <= kEmitSolo) {
         for (int ty = y0; ty < y1; ty++)
             for (int tx = x0; tx < x1; tx++) {
@@ -664,14 +689,15 @@ GSX_API int gsx_bin_emit_sort(const float* rec, const uint32_t* tile_box, const 
                               uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, void* stream)
 {
     return gsx::bin_emit_sort_impl(rec, tile_box, offsets, N, H, W, capacity, total_dev, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp,
-                                   ranges, chunk_base, chunk_force, ws, ws_bytes, nullptr, stream);
+                                   ranges, chunk_base, chunk_force, ws, ws_bytes, nullptr, stream, nullptr);
 }
 
 // info (nullable, device-visible pinned host memory): images of up to 4096 tiles leave 1 + their number of empty tiles there
 int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                             int64_t capacity, const uint64_t* total_dev,
                             uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                            uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream)
+                            uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream,
+                            const EmitScan* scan)
 {
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || capacity <= 0) return GSX_E_INVALID;
     if (chunk_force != 0 && chunk_force != 64 && chunk_force != 128 && chunk_force != 256) return GSX_E_INVALID;
@@ -679,11 +705,20 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
     if (!ranges || !chunk_base || !total_dev || !ws || ws_bytes < gsx_bin_workspace_bytes(N, capacity)) return GSX_E_INVALID;
     if (!tiles_sorted || !ranks_sorted || !tiles_tmp || !ranks_tmp) return GSX_E_INVALID;
     if (N > 0 && (!rec || !offsets)) return GSX_E_INVALID;
+    if (scan && (N <= 0 || !scan->sums || !scan->offsets_out || scan->offsets_out != offsets || scan->total != total_dev)) return GSX_E_INVALID;
     if (W > 256 * GSX_TILE || H > 256 * GSX_TILE) tile_box = nullptr;       // the packed boxes hold 8-bit tile coordinates
     hipStream_t st = (hipStream_t)stream;
     const int tw = (W + GSX_TILE - 1) / GSX_TILE, th = (H + GSX_TILE - 1) / GSX_TILE, n_tiles = tw * th;
     void* sub_ws = (char*)ws + 256; size_t sub_bytes = ws_bytes - 256;
     const int bits = tile_bits(n_tiles);
+    // scan != nullptr (N > 0): offsets[] and *total_dev are this call's to write (emit_kernel<true>)
+    auto launch_emit = [&](uint32_t* e_tiles, uint32_t* e_ranks) {
+        const dim3 grid((unsigned)ceil_div(N, kBlock));
+        if (scan) emit_kernel<true><<<grid, dim3(kBlock), 0, st>>>(rec, tile_box, nullptr, N, tw, (uint32_t)capacity, e_tiles, e_ranks,
+                                                                   scan->sums, scan->offsets_out, scan->total, scan->mirror);
+        else emit_kernel<false><<<grid, dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, e_tiles, e_ranks,
+                                                               nullptr, nullptr, nullptr, nullptr);
+    };
     if (n_tiles <= kTsDigits) {
         // one 12-bit pass; ranges and chunk table come out of the scatter's workgroup 0
         // grid for the largest workgroup count any instance count <= capacity can need (fewer instances -> fewer keys per
@@ -695,7 +730,7 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
         uint32_t* hist = (uint32_t*)sub_ws;
         uint32_t* totals = (uint32_t*)((char*)sub_ws + align_up((size_t)nb * kTsDigits * 4));
         if (N > 0) {
-            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
+            launch_emit(tiles_tmp, ranks_tmp);
             tile_hist_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
         }
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
@@ -713,7 +748,7 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
         uint32_t* hist = (uint32_t*)sub_ws;
         uint32_t* totals = (uint32_t*)((char*)sub_ws + align_up((size_t)nb * kWsDigits * 4));
         if (N > 0) {
-            emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, tiles_tmp, ranks_tmp);
+            launch_emit(tiles_tmp, ranks_tmp);
             wtile_hist_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
         }
         wtile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
@@ -727,7 +762,7 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
     uint32_t* e_t = (passes & 1) ? tiles_tmp : tiles_sorted;
     uint32_t* e_r = (passes & 1) ? ranks_tmp : ranks_sorted;
     if (N > 0) {
-        emit_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, st>>>(rec, tile_box, offsets, N, tw, (uint32_t)capacity, e_t, e_r);
+        launch_emit(e_t, e_r);
         GSX_LAUNCH_CHECK();
         int s = sort_pairs_internal(e_t, e_r, tiles_sorted, ranks_sorted, tiles_tmp, ranks_tmp, capacity, total_dev, 0, bits, sub_ws, sub_bytes, st);
         if (s != GSX_OK) return s;

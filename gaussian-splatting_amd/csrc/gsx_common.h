@@ -90,12 +90,45 @@ int preprocess_bwd_with_loss(const float* positions, const float* scales, const 
                              const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                              int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
                              float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials, void* stream);
+#ifdef __HIPCC__
+// (gsx_sort.hip's scans and the emit kernel's)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + incl - v;
+}
+#endif
+
 // gsx_bin_emit_sort with a pinned host word for the number of empty tiles; gsx_composite_fwd in two parts (which: 1 = the view's
 // compositing, 2 = the global-exit path behind it -- search, second chunk pass, second combine pass --, 3 = both)
+// scan (nullable; N > 0): the emit kernel scans the tile counts itself instead of reading offsets[] (no gsx_bin_count in front of this
+// call): sums = gsx_build_records' tt_block_sums, offsets_out = the `offsets` argument (written here), total = the `total_dev`
+// argument (written here), mirror = device view of two pinned host words for the total and the word behind it, or nullptr
+struct EmitScan { const uint64_t* sums; uint32_t* offsets_out; uint64_t* total; uint64_t* mirror; };
 int bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                        int64_t capacity, const uint64_t* total_dev,
                        uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,
-                       uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream);
+                       uint32_t* ranges, uint32_t* chunk_base, int32_t chunk_force, void* ws, size_t ws_bytes, uint64_t* info, void* stream,
+                       const EmitScan* scan = nullptr);
 int composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
                        const uint32_t* chunk_base, int32_t N, int32_t H, int32_t W,
                        int64_t max_chunks, float* chunk_state, int32_t need_bwd, uint32_t* state,

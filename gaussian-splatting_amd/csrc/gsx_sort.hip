@@ -19,31 +19,6 @@ thread_local int g_last_hip_error = 0;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;   // 2048
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
-__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan_u32(v);
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-    uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
-    *total = w0 + w1 + w2 + w3;
-    __syncthreads();
-    return base + incl - v;
-}
-
 __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ block_sums)
 {
     __shared__ uint64_t s_w[4];

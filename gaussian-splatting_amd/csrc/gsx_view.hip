@@ -143,24 +143,33 @@ static int view_forward_impl(const float* positions, const float* scales, const 
     st = gsx_build_records(f32(GSX_VIEW_PRE), order, N, H, W, f32(GSX_VIEW_REC), u32(GSX_VIEW_TILES_TOUCHED), u32(GSX_VIEW_RANK_OF),
                            u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_TILE_BOX), stream);
     if (st != GSX_OK) return st;
-    st = gsx_bin_count(u32(GSX_VIEW_TILES_TOUCHED), u64(GSX_VIEW_TT_BLOCK_SUMS), N, u32(GSX_VIEW_OFFSETS), total, D_pinned_host,
-                       raw(GSX_VIEW_SCAN_WS), gsx_scan_workspace_bytes(N), stream);
-    if (st != GSX_OK) return st;
-    // the host may read D (and the sort's mismatch count) as soon as THIS point of the stream is reached, long before the
-    // compositing enqueued below has run
-    if (count_event && !late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
-    uint64_t* info = nullptr;
-    if (late && D_pinned_host && N > 0) {
+    // The scan of the tile counts rides in the emit kernel (one dependent launch less) when the instance count can reach the host
+    // from that kernel: pinned words the device can address (what torch's pin_memory() gives), or nobody asking for it.
+    uint64_t* pinned_dev = nullptr;
+    if (D_pinned_host && N > 0) {
         void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, D_pinned_host, 0) == hipSuccess) info = static_cast<uint64_t*>(dp) + 2;
+        if (hipHostGetDevicePointer(&dp, D_pinned_host, 0) == hipSuccess) pinned_dev = static_cast<uint64_t*>(dp);
         else (void)hipGetLastError();
     }
+    const bool scan_in_emit = N > 0 && (pinned_dev || !D_pinned_host);
+    if (!scan_in_emit) {
+        st = gsx_bin_count(u32(GSX_VIEW_TILES_TOUCHED), u64(GSX_VIEW_TT_BLOCK_SUMS), N, u32(GSX_VIEW_OFFSETS), total, D_pinned_host,
+                           raw(GSX_VIEW_SCAN_WS), gsx_scan_workspace_bytes(N), stream);
+        if (st != GSX_OK) return st;
+        // the host may read D (and the sort's mismatch count) as soon as THIS point of the stream is reached, long before the
+        // compositing enqueued below has run
+        if (count_event && !late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
+    }
+    uint64_t* info = (late && pinned_dev) ? pinned_dev + 2 : nullptr;
+    const gsx::EmitScan scan = { u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_OFFSETS), total, pinned_dev };
     st = gsx::bin_emit_sort_impl(f32(GSX_VIEW_REC), u32(GSX_VIEW_TILE_BOX), u32(GSX_VIEW_OFFSETS), N, H, W, capacity, total,
                                  u32(GSX_VIEW_TILES_SORTED), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_TILES_TMP), u32(GSX_VIEW_RANKS_TMP),
                                  u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), chunk_force,
-                                 raw(GSX_VIEW_BIN_WS), gsx_bin_workspace_bytes(N, capacity), info, stream);
+                                 raw(GSX_VIEW_BIN_WS), gsx_bin_workspace_bytes(N, capacity), info, stream, scan_in_emit ? &scan : nullptr);
     if (st != GSX_OK) return st;
-    if (count_event && late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
+    // (with the scan in the emit kernel the count is on its way from the binning stage's first kernel: the event stands behind the
+    // stage, three short kernels later than it used to)
+    if (count_event && (late || scan_in_emit)) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
     return gsx::composite_fwd_impl(f32(GSX_VIEW_REC), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), N, H, W,
                                    L.max_chunks, f32(GSX_VIEW_CHUNK_STATE), need_bwd ? 1 : 0, state,
                                    rgb, alpha, depth_map, late ? 1 : 3, stream);

@@ -197,8 +197,9 @@ int gsx_composite_fwd(const float* rec, const uint32_t* ranks_sorted, const uint
  *   depth_bits = 32, or GSX_DEPTH_CHECK_BIT if the previous view's mismatch count was 0 (see gsx_sort_pairs_u32);
  *   given_order (nullable) = a depth order to use instead of sorting (views after the first of a batch, :206).  The
  *   instance count D and the mismatch count land in arena[GSX_VIEW_TOTAL] (2 x u64) and, if D_pinned_host != NULL, in
- *   16 bytes of pinned host memory; count_event (nullable hipEvent_t) is recorded right behind that copy, BEFORE binning
- *   and compositing are enqueued, so the host can learn D while the GPU is still busy with the view.  As with
+ *   16 bytes of pinned host memory; count_event (nullable hipEvent_t) is recorded behind the binning stage, BEFORE
+ *   compositing is enqueued, so the host can learn D while the GPU is still busy with the view (the scan of the tile counts
+ *   rides in the binning stage's first kernel, which writes the pinned words itself when the device can address them).  As with
  *   gsx_bin_emit_sort, D > capacity truncates the results (never out of bounds): the caller checks D and calls again
  *   with a larger block.  Buffers GSX_VIEW_ORDER .. GSX_VIEW_TOTAL are what gsx_composite_bwd / gsx_preprocess_bwd read;
  *   `state` (gsx_composite_fwd's, 16 bytes) stays outside the block because callers keep it (the exit rank is an output). */
