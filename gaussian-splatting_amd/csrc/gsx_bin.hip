@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kTsThreads) void tile_scatter_kernel(const uint32_t
         if (k < items && i < here) {
             const uint32_t d = s_key[i];
             const uint32_t dst = s_base[d] + i;
-            keys_out[dst] = d;
+            if (keys_out) keys_out[dst] = d;              // (the view driver asks for no sorted keys: nothing reads them)
             vals_out[dst] = s_val[i];
         }
     }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kWsThreads) void wtile_scatter_kernel(const uint32_
         if (k < items && i < here) {
             const uint32_t d = s_key[i];
             const uint32_t dst = s_base[d] + i;
-            keys_out[dst] = d;
+            if (keys_out) keys_out[dst] = d;              // (the view driver asks for no sorted keys: nothing reads them)
             vals_out[dst] = s_val[i];
         }
     }
@@ -734,7 +734,7 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
             tile_hist_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
         }
         tile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
-        tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
+        tile_scatter_kernel<<<dim3(nb), dim3(kTsThreads), 0, st>>>(tiles_tmp, ranks_tmp, (scan && scan->no_sorted_keys) ? nullptr : tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
                                                                     hist, totals, chunk_force, ranges, chunk_base, info);
         GSX_LAUNCH_CHECK();
         return GSX_OK;
@@ -752,7 +752,7 @@ int gsx::bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const ui
             wtile_hist_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, total_dev, capacity, n_tiles, hist);
         }
         wtile_colscan_kernel<<<dim3((unsigned)ceil_div(n_tiles, kTsSegDigits)), dim3(kTsThreads), 0, st>>>(hist, total_dev, capacity, n_tiles, totals);
-        wtile_scatter_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, ranks_tmp, tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
+        wtile_scatter_kernel<<<dim3(nb), dim3(kWsThreads), 0, st>>>(tiles_tmp, ranks_tmp, (scan && scan->no_sorted_keys) ? nullptr : tiles_sorted, ranks_sorted, total_dev, capacity, n_tiles,
                                                                      hist, totals, chunk_force, ranges, chunk_base);
         GSX_LAUNCH_CHECK();
         return GSX_OK;

@@ -123,7 +123,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_
 // scan (nullable; N > 0): the emit kernel scans the tile counts itself instead of reading offsets[] (no gsx_bin_count in front of this
 // call): sums = gsx_build_records' tt_block_sums, offsets_out = the `offsets` argument (written here), total = the `total_dev`
 // argument (written here), mirror = device view of two pinned host words for the total and the word behind it, or nullptr
-struct EmitScan { const uint64_t* sums; uint32_t* offsets_out; uint64_t* total; uint64_t* mirror; };
+// no_sorted_keys: the one-pass tile sorts leave tiles_sorted unwritten (compositing reads ranges and ranks_sorted only)
+struct EmitScan { const uint64_t* sums; uint32_t* offsets_out; uint64_t* total; uint64_t* mirror; int no_sorted_keys; };
 int bin_emit_sort_impl(const float* rec, const uint32_t* tile_box, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
                        int64_t capacity, const uint64_t* total_dev,
                        uint32_t* tiles_sorted, uint32_t* ranks_sorted, uint32_t* tiles_tmp, uint32_t* ranks_tmp,

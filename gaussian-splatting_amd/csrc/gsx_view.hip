@@ -161,7 +161,7 @@ static int view_forward_impl(const float* positions, const float* scales, const 
         if (count_event && !late) GSX_HIP(hipEventRecord(static_cast<hipEvent_t>(count_event), static_cast<hipStream_t>(stream)));
     }
     uint64_t* info = (late && pinned_dev) ? pinned_dev + 2 : nullptr;
-    const gsx::EmitScan scan = { u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_OFFSETS), total, pinned_dev };
+    const gsx::EmitScan scan = { u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_OFFSETS), total, pinned_dev, late ? 1 : 0 };      // (the one-call step: nobody looks at the sorted tile ids; half the scatter's stores)
     st = gsx::bin_emit_sort_impl(f32(GSX_VIEW_REC), u32(GSX_VIEW_TILE_BOX), u32(GSX_VIEW_OFFSETS), N, H, W, capacity, total,
                                  u32(GSX_VIEW_TILES_SORTED), u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_TILES_TMP), u32(GSX_VIEW_RANKS_TMP),
                                  u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), chunk_force,
