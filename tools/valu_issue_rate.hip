@@ -59,13 +59,13 @@ constexpr int kIters = 2000;
     "v_rcp_f32 %10, %10\n\t v_cndmask_b32 %11, %11, %12, vcc\n\t v_mul_f32 %13, %13, %16\n\t v_sub_f32 %14, %14, %16\n\t" \
     "v_ldexp_f32 %15, %15, 0\n\t v_mul_f32 %0, %0, %16\n\t v_mul_f32 %1, %1, %16\n\t v_add_f32 %3, %3, %16\n\t"
 
-enum Body { B_FMA, B_FMA_DEP, B_EXP, B_MIX_1EXP_IN_16, B_MIX_BWD, B_DPP, B_SWAP, B_FMA_NOP, B_FMA_SALU, B_FMA_BRANCH, B_FMA_LDS, B_MISC, B_COUNT };
+enum Body { B_FMA, B_FMA_DEP, B_EXP, B_MIX_1EXP_IN_16, B_MIX_BWD, B_DPP, B_SWAP, B_FMA_NOP, B_FMA_SALU, B_FMA_BRANCH, B_FMA_LDS, B_MISC, B_PK_ADD, B_COUNT };
 static const char* kNames[B_COUNT] = {
     "32 v_fma_f32 independent", "32 v_fma_f32 one dependent chain", "32 v_exp_f32 independent", "30 v_fma + 2 v_exp (1 in 16)",
     "26 v_fma + 2 v_exp + 2 v_rcp + 2 s_nop (bwd-like)", "32 v_add_f32_dpp independent", "16 fma + 16 v_permlane{32,16}_swap", "28 v_fma + 4 s_nop 0",
     "32 v_fma + 16 s_and_b64 (48 instr)", "32 v_fma + 8 (s_bitcmp + s_cbranch not taken) (48 instr)", "32 v_fma + 3 ds_read_b128 bcast + wait (36 instr)",
-    "16 ldexp/frexp/max_u32/rcp/cndmask/mul + 16 fma" };
-static const int kInstr[B_COUNT] = { 32, 32, 32, 32, 32, 32, 32, 32, 48, 48, 36, 32 };
+    "16 ldexp/frexp/max_u32/rcp/cndmask/mul + 16 fma", "32 v_pk_add_f32 independent (64 adds)" };
+static const int kInstr[B_COUNT] = { 32, 32, 32, 32, 32, 32, 32, 32, 48, 48, 36, 32, 32 };
 
 template <int BODY>
 __global__ __launch_bounds__(256) void issue_kernel(float* out, uint64_t* cycles, float seed)
@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256) void issue_kernel(float* out, uint64_t* cycles
     if (BODY == B_FMA_LDS) { lds[threadIdx.x & 63] = make_float4(seed, seed, seed, seed); __syncthreads(); }
     unsigned long long sm = 0x5555555555555555ull + (unsigned long long)(seed > 2.0f);
     float4 l0 = {0, 0, 0, 0}, l1 = l0, l2 = l0;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f pk[8], pks = { s * 1e-3f, s * 2e-3f };
+#pragma unroll
+    for (int i = 0; i < 8; i++) pk[i] = v2f{ v[2 * i], v[2 * i + 1] };
     const uint32_t ldsaddr = 0;
     __syncthreads();
     const uint64_t t0 = __builtin_readcyclecounter();
@@ -107,12 +111,16 @@ __global__ __launch_bounds__(256) void issue_kernel(float* out, uint64_t* cycles
         if (BODY == B_FMA_LDS) asm volatile(
             "ds_read_b128 %17, %20\n\t ds_read_b128 %18, %20 offset:16\n\t ds_read_b128 %19, %20 offset:32\n\t" FMA16 FMA16 "s_waitcnt lgkmcnt(0)\n\t"
             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(s), "=&v"(l0), "=&v"(l1), "=&v"(l2) : "v"(ldsaddr) : "memory");
+        if (BODY == B_PK_ADD) asm volatile(R4("v_pk_add_f32 %0, %0, %8\n\t v_pk_add_f32 %1, %1, %8\n\t v_pk_add_f32 %2, %2, %8\n\t v_pk_add_f32 %3, %3, %8\n\t"
+                                              "v_pk_add_f32 %4, %4, %8\n\t v_pk_add_f32 %5, %5, %8\n\t v_pk_add_f32 %6, %6, %8\n\t v_pk_add_f32 %7, %7, %8\n\t")
+                                           : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]) : "v"(pks));
         if (BODY == B_MISC) asm volatile(MISC16 FMA16 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : "v"(s) : "vcc");
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     float acc = l0.x + l1.y + l2.z + (float)(sm & 1ull);
 #pragma unroll
     for (int i = 0; i < 16; i++) acc += v[i];
+    if (BODY == B_PK_ADD) { for (int i = 0; i < 8; i++) acc += pk[i].x + pk[i].y; }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -170,6 +178,7 @@ int main()
     if (run_body<B_FMA_BRANCH>(out, cyc, n_cu, &mhz)) return 1;
     if (run_body<B_FMA_LDS>(out, cyc, n_cu, &mhz)) return 1;
     if (run_body<B_MISC>(out, cyc, n_cu, &mhz)) return 1;
+    if (run_body<B_PK_ADD>(out, cyc, n_cu, &mhz)) return 1;
     printf("counter ticks per microsecond of wall time (fma body, W=4): %.0f\n", mhz);
     return 0;
 }
