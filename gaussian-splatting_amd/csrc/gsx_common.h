@@ -89,7 +89,8 @@ int preprocess_bwd_with_loss(const float* positions, const float* scales, const 
                              const float* pose, const uint32_t* rank_of, const uint32_t* offsets,
                              const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                              int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
-                             float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials, void* stream);
+                             float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials,
+                             const uint64_t* vis /* nullable: project_fwd_impl's bitmap; rank_of then holds visible Gaussians only */, void* stream);
 #ifdef __HIPCC__
 // (gsx_sort.hip's scans and the emit kernel's)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
@@ -118,6 +119,15 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_
 }
 #endif
 
+// gsx_project_fwd / gsx_build_records with the visibility bitmap of the one-call trainer step (vis: one bit per Gaussian, N / 64 words
+// rounded up; H, W: the image the footprints are cut against).  vis == nullptr: the public entry points' behaviour
+int project_fwd_impl(const float* positions, const float* scales, const float* rotations,
+                     const float* opacity, const float* features, const float* pose, int32_t N,
+                     float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, float* pre,
+                     int32_t H, int32_t W, uint64_t* vis, void* stream);
+int build_records_impl(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
+                       float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, uint32_t* tile_box,
+                       const uint64_t* vis, void* stream);
 // gsx_bin_emit_sort with a pinned host word for the number of empty tiles; gsx_composite_fwd in two parts (which: 1 = the view's
 // compositing, 2 = the global-exit path behind it -- search, second chunk pass, second combine pass --, 3 = both)
 // scan (nullable; N > 0): the emit kernel scans the tile counts itself instead of reading offsets[] (no gsx_bin_count in front of this

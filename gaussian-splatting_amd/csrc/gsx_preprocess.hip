@@ -88,66 +88,15 @@ __device__ __forceinline__ float inv2x2(float a, float b, float c, float d, floa
     }
 }
 
-__global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ scl,
-                                                             const float* __restrict__ rot, const float* __restrict__ opacity,
-                                                             const float* __restrict__ features, const float* __restrict__ pose, int N,
-                                                             float* __restrict__ mean2d, float* __restrict__ depth,
-                                                             float* __restrict__ cov2d, uint32_t* __restrict__ key,
-                                                             float4* __restrict__ pre)
+// footprint box in pixels (bit-exact contract with oracle footprint()); empty: xlo > xhi.  a, d: the covariance's diagonal WITH
+// GSX_COV_EPS, det: inv2x2's determinant of it
+__device__ __forceinline__ void footprint_box(float2 mu, float a, float d, float det, float op, int H, int W,
+                                              int& xlo, int& ylo, int& xhi, int& yhi)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= N) return;
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = pose[k];
-    const float p[3] = { pos[3*i], pos[3*i+1], pos[3*i+2] };
-    const float s[3] = { scl[3*i], scl[3*i+1], scl[3*i+2] };
-    const float4 qv = reinterpret_cast<const float4*>(rot)[i];
-    const float q[4] = { qv.x, qv.y, qv.z, qv.w };
-    Proj o; project_one(p, s, q, M, o);
-    if (mean2d) {       // the reference's returned tensors: a caller that never looks at them (a trainer step with an image-only criterion) passes none
-        reinterpret_cast<float2*>(mean2d)[i] = make_float2(o.mx, o.my);
-        depth[i] = o.depth;
-        reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
-    }
-    key[i] = depth_key(o.depth);
-    // packed copy of everything build_records needs: ONE 48-byte row to gather per Gaussian instead of
-    // five scattered lines (mean2d, depth, cov2d, opacity, features)
-    float4* P = pre + (size_t)3 * i;
-    P[0] = make_float4(o.mx, o.my, o.cov[0], o.cov[1]);
-    P[1] = make_float4(o.cov[2], o.cov[3], o.depth, opacity[i]);
-    P[2] = make_float4(features[3*i], features[3*i+1], features[3*i+2], 0.0f);
-}
-
-// tt_sums (nullable): per-workgroup sum of tiles_touched, so that the scan that follows is one launch (gsx_bin_count)
-__device__ __forceinline__ void block_sum_tiles(uint32_t tt, uint64_t* __restrict__ tt_sums)
-{
-    __shared__ uint32_t s_tt[kBlock / 64];
-    uint32_t s = tt;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);          // <= 64 * (4096^2 tiles) would wrap: summed per wave in
-    if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = s;              // u32 only for images up to 8192 tiles (checked on the host)
-    __syncthreads();
-    if (threadIdx.x == 0) tt_sums[blockIdx.x] = ((uint64_t)s_tt[0] + s_tt[1]) + ((uint64_t)s_tt[2] + s_tt[3]);
-}
-
-// one rank: gathers the Gaussian's packed row, writes its record, footprint and inverse-order entry; returns tiles_touched
-__device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ pre, const uint32_t* __restrict__ order, int r,
-                                                     int H, int W, float* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                                                     uint32_t* __restrict__ rank_of, uint32_t* __restrict__ tile_box)
-{
-    const uint32_t g = order[r];
-    rank_of[g] = (uint32_t)r;
-    const float4 p0 = pre[(size_t)3 * g], p1 = pre[(size_t)3 * g + 1], p2 = pre[(size_t)3 * g + 2];
-    const float2 mu = make_float2(p0.x, p0.y);
-    const float a = p0.z + GSX_COV_EPS, b = p0.w, c = p1.x, d = p1.y + GSX_COV_EPS;
-    float m[4]; const float det = inv2x2(a, b, c, d, m);
-    const float op = p1.w;
-    // footprint box (bit-exact contract with oracle footprint())
     uint32_t ob = __float_as_uint(op) & 0x7fffffffu;
     const int e = max((int)(ob >> 23) - 127, GSX_CUT_MIN_EXP_FOR(H, W));
     const int mm = e + 1 + GSX_CUT_LOG2_FOR(H, W);
-    int xlo = 1, ylo = 1, xhi = 0, yhi = 0;
+    xlo = 1; ylo = 1; xhi = 0; yhi = 0;
     if (!(ob < 0x7f800000u && mm <= 0)) {
         bool full = !(ob < 0x7f800000u);
         const float kap2 = GSX_TWO_LN2 * (float)mm;
@@ -164,6 +113,94 @@ __device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ 
             if ((fxlo <= fxhi) && (fylo <= fyhi)) { xlo = (int)fxlo; ylo = (int)fylo; xhi = (int)fxhi; yhi = (int)fyhi; }
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ scl,
+                                                             const float* __restrict__ rot, const float* __restrict__ opacity,
+                                                             const float* __restrict__ features, const float* __restrict__ pose, int N,
+                                                             float* __restrict__ mean2d, float* __restrict__ depth,
+                                                             float* __restrict__ cov2d, uint32_t* __restrict__ key,
+                                                             float4* __restrict__ pre, int H, int W, uint64_t* __restrict__ vis)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < N;
+    if (!live && !vis) return;
+    bool visible = false;
+    if (live) {
+    float M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = pose[k];
+    const float p[3] = { pos[3*i], pos[3*i+1], pos[3*i+2] };
+    const float s[3] = { scl[3*i], scl[3*i+1], scl[3*i+2] };
+    const float4 qv = reinterpret_cast<const float4*>(rot)[i];
+    const float q[4] = { qv.x, qv.y, qv.z, qv.w };
+    Proj o; project_one(p, s, q, M, o);
+    if (mean2d) {       // the reference's returned tensors: a caller that never looks at them (a trainer step with an image-only criterion) passes none
+        reinterpret_cast<float2*>(mean2d)[i] = make_float2(o.mx, o.my);
+        depth[i] = o.depth;
+        reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
+    }
+    key[i] = depth_key(o.depth);
+    const float op = opacity[i];
+    visible = true;
+    if (vis) {
+        // does the splat touch the image at all?  build_records' own test (footprint_box on the numbers the packed row would carry)
+        const float a = o.cov[0] + GSX_COV_EPS, b = o.cov[1], c = o.cov[2], d = o.cov[3] + GSX_COV_EPS;
+        float m[4]; const float det = inv2x2(a, b, c, d, m);
+        int xlo, ylo, xhi, yhi;
+        footprint_box(make_float2(o.mx, o.my), a, d, det, op, H, W, xlo, ylo, xhi, yhi);
+        visible = xlo <= xhi;
+    }
+    // packed copy of everything build_records needs: ONE 48-byte row to gather per Gaussian instead of
+    // five scattered lines (mean2d, depth, cov2d, opacity, features); with `vis`, only for those it will gather
+    if (visible) {
+        float4* P = pre + (size_t)3 * i;
+        P[0] = make_float4(o.mx, o.my, o.cov[0], o.cov[1]);
+        P[1] = make_float4(o.cov[2], o.cov[3], o.depth, op);
+        P[2] = make_float4(features[3*i], features[3*i+1], features[3*i+2], 0.0f);
+    }
+    }
+    if (vis) {
+        const unsigned long long bits = __ballot(visible);               // (whole waves reach this: i is wave-aligned)
+        if ((threadIdx.x & 63) == 0 && (i >> 6) < (N + 63) / 64) vis[i >> 6] = bits;
+    }
+}
+
+// tt_sums (nullable): per-workgroup sum of tiles_touched, so that the scan that follows is one launch (gsx_bin_count)
+__device__ __forceinline__ void block_sum_tiles(uint32_t tt, uint64_t* __restrict__ tt_sums)
+{
+    __shared__ uint32_t s_tt[kBlock / 64];
+    uint32_t s = tt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);          // <= 64 * (4096^2 tiles) would wrap: summed per wave in
+    if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = s;              // u32 only for images up to 8192 tiles (checked on the host)
+    __syncthreads();
+    if (threadIdx.x == 0) tt_sums[blockIdx.x] = ((uint64_t)s_tt[0] + s_tt[1]) + ((uint64_t)s_tt[2] + s_tt[3]);
+}
+
+// one rank: gathers the Gaussian's packed row, writes its record, footprint and inverse-order entry; returns tiles_touched.
+// vis (nullable; the one-call trainer step): one bit per GAUSSIAN, set by the projection kernel for those whose footprint box is not
+// empty (the same function on the same numbers) -- a rank whose bit is clear gets its empty footprint without the 48-byte gather and
+// no record (nothing reads the record of a splat without instances); on the bench orbit that is 45 % of the ranks
+__device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ pre, const uint32_t* __restrict__ order, int r,
+                                                     int H, int W, float* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+                                                     uint32_t* __restrict__ rank_of, uint32_t* __restrict__ tile_box,
+                                                     const uint64_t* __restrict__ vis)
+{
+    const uint32_t g = order[r];
+    if (vis && !((vis[g >> 6] >> (g & 63u)) & 1ull)) {       // (not even its rank_of entry: the backward asks the bitmap first)
+        tiles_touched[r] = 0u;
+        if (tile_box) tile_box[r] = 0x00000001u;
+        return 0u;
+    }
+    rank_of[g] = (uint32_t)r;                                // (a 4-byte scatter: the most expensive store of this kernel)
+    const float4 p0 = pre[(size_t)3 * g], p1 = pre[(size_t)3 * g + 1], p2 = pre[(size_t)3 * g + 2];
+    const float2 mu = make_float2(p0.x, p0.y);
+    const float a = p0.z + GSX_COV_EPS, b = p0.w, c = p1.x, d = p1.y + GSX_COV_EPS;
+    float m[4]; const float det = inv2x2(a, b, c, d, m);
+    const float op = p1.w;
+    int xlo, ylo, xhi, yhi;
+    footprint_box(mu, a, d, det, op, H, W, xlo, ylo, xhi, yhi);
     uint32_t tt = 0;
     if (xlo <= xhi) tt = (uint32_t)(((xhi >> GSX_TILE_SHIFT) + 1 - (xlo >> GSX_TILE_SHIFT)) * ((yhi >> GSX_TILE_SHIFT) + 1 - (ylo >> GSX_TILE_SHIFT)));
     tiles_touched[r] = tt;
@@ -182,10 +219,11 @@ __device__ __forceinline__ uint32_t build_record_one(const float4* __restrict__ 
 __global__ __launch_bounds__(kBlock) void build_records_kernel(const float4* __restrict__ pre, const uint32_t* __restrict__ order,
                                                                int N, int H, int W, float* __restrict__ rec,
                                                                uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ rank_of,
-                                                               uint64_t* __restrict__ tt_sums, uint32_t* __restrict__ tile_box)
+                                                               uint64_t* __restrict__ tt_sums, uint32_t* __restrict__ tile_box,
+                                                               const uint64_t* __restrict__ vis)
 {
     const int r = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t tt = (r < N) ? build_record_one(pre, order, r, H, W, rec, tiles_touched, rank_of, tile_box) : 0u;
+    const uint32_t tt = (r < N) ? build_record_one(pre, order, r, H, W, rec, tiles_touched, rank_of, tile_box, vis) : 0u;
     if (tt_sums) block_sum_tiles(tt, tt_sums);          // every thread of the workgroup reaches the barrier inside
 }
 
@@ -202,7 +240,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float* __restrict__ d_mean2d, const float* __restrict__ d_depth, const float* __restrict__ d_cov2d,
     int N, int accumulate,
     float* __restrict__ g_pos, float* __restrict__ g_scl, float* __restrict__ g_rot, float* __restrict__ g_opa, float* __restrict__ g_fea,
-    const double* __restrict__ loss_partials, long long loss_n, float* __restrict__ loss, double* __restrict__ norm_partials)
+    const double* __restrict__ loss_partials, long long loss_n, float* __restrict__ loss, double* __restrict__ norm_partials,
+    const uint64_t* __restrict__ vis)
 {
     if (loss && blockIdx.x == gridDim.x - 1) {
         // the one-call trainer step's loss value: gsx_loss.hip's loss_final_kernel, same order of summation (same bits), by
@@ -218,13 +257,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     int g = blockIdx.x * kBlock + threadIdx.x;              // N is rounded up to whole waves below: no early return before the shuffles
     const int lane = threadIdx.x & 63;
     const bool live = g < N;
-    const uint32_t r = live ? rank_of[g] : 0u;
+    // vis (the one-call trainer step): the projection kernel's bitmap of the Gaussians whose footprint touches the image; the others
+    // have no rows, and the records stage left no rank for them
+    const bool seen = live && (!vis || ((vis[g >> 6] >> (g & 63)) & 1ull));
+    const uint32_t r = seen ? rank_of[g] : 0u;
     float D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t limit = (uint32_t)N;
     if (state) { const uint32_t s = state[0]; if (s != GSX_RANK_NONE && s + 1u < (uint32_t)N) limit = s + 1u; }
     uint32_t o0 = 0, tt = 0;
     // the splat's row count is the next offset minus its own (same 64-byte line 15 times in 16): one random gather, not two
-    if (live && partials && r < limit) { o0 = offsets[r]; tt = (r + 1u < (uint32_t)N) ? offsets[r + 1u] - o0 : tiles_touched[r]; }
+    if (seen && partials && r < limit) { o0 = offsets[r]; tt = (r + 1u < (uint32_t)N) ? offsets[r + 1u] - o0 : tiles_touched[r]; }
     // rows of a splat: summed by its own lane in tile order when there are few; a splat with more than kRowsSolo rows
     // is summed by the whole wavefront (lane l takes rows l, l+64, ... in order, then a fixed butterfly): a
     // screen-sized splat would otherwise serialise thousands of loads in one lane.  Both orders are fixed, so the
@@ -394,14 +436,23 @@ GSX_API int gsx_project_fwd(const float* positions, const float* scales, const f
                             const float* opacity, const float* features, const float* pose, int32_t N,
                             float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, float* pre, void* stream)
 {
+    return gsx::project_fwd_impl(positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d, depth_key, pre, 0, 0, nullptr, stream);
+}
+
+int gsx::project_fwd_impl(const float* positions, const float* scales, const float* rotations,
+                          const float* opacity, const float* features, const float* pose, int32_t N,
+                          float* mean2d, float* depth, float* cov2d, uint32_t* depth_key, float* pre,
+                          int32_t H, int32_t W, uint64_t* vis, void* stream)
+{
     if (N < 0) return GSX_E_INVALID;
+    if (vis && (H <= 0 || W <= 0 || ((uintptr_t)vis & 7u))) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
     if (!positions || !scales || !rotations || !opacity || !features || !pose || !depth_key || !pre) return GSX_E_INVALID;
     if ((mean2d || depth || cov2d) && !(mean2d && depth && cov2d)) return GSX_E_INVALID;      // all three outputs, or none
     if (((uintptr_t)rotations | (uintptr_t)cov2d | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
     if ((uintptr_t)mean2d & 7u) return GSX_E_INVALID;
     project_fwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d, depth_key, (float4*)pre);
+        positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d, depth_key, (float4*)pre, H, W, vis);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -410,15 +461,24 @@ GSX_API int gsx_build_records(const float* pre, const uint32_t* order, int32_t N
                               float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, uint32_t* tile_box,
                               void* stream)
 {
+    return gsx::build_records_impl(pre, order, N, H, W, rec, tiles_touched, rank_of, tt_block_sums, tile_box, nullptr, stream);
+}
+
+int gsx::build_records_impl(const float* pre, const uint32_t* order, int32_t N, int32_t H, int32_t W,
+                            float* rec, uint32_t* tiles_touched, uint32_t* rank_of, uint64_t* tt_block_sums, uint32_t* tile_box,
+                            const uint64_t* vis, void* stream)
+{
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return GSX_E_INVALID;
     if (N == 0) return GSX_OK;
     if (!pre || !order || !rec || !tiles_touched || !rank_of) return GSX_E_INVALID;
     if (((uintptr_t)rec | (uintptr_t)pre) & 15u) return GSX_E_INVALID;
+    // without the packed tile boxes the emit pass reads the footprint from the RECORD: every rank needs one
+    if (vis && !(tile_box && W <= 256 * GSX_TILE && H <= 256 * GSX_TILE)) return GSX_E_INVALID;
     // the per-wave partial sums are u32: 64 splats x n_tiles must fit
     if (tt_block_sums && (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE) > (int64_t)(0xFFFFFFFFu / 64u)) return GSX_E_RANGE;
     build_records_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         (const float4*)pre, order, N, H, W, rec, tiles_touched, rank_of, tt_block_sums,
-        (W <= 256 * GSX_TILE && H <= 256 * GSX_TILE) ? tile_box : nullptr);
+        (W <= 256 * GSX_TILE && H <= 256 * GSX_TILE) ? tile_box : nullptr, vis);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -440,7 +500,7 @@ GSX_API int gsx_preprocess_bwd(const float* positions, const float* scales, cons
     if (d_cov2d && ((uintptr_t)d_cov2d & 15u)) return GSX_E_INVALID;
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
-        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features, nullptr, 0, nullptr, nullptr);
+        d_mean2d, d_depth, d_cov2d, N, accumulate, g_positions, g_scales, g_rotations, g_opacity, g_features, nullptr, 0, nullptr, nullptr, nullptr);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }
@@ -452,7 +512,7 @@ int gsx::preprocess_bwd_with_loss(const float* positions, const float* scales, c
                                   const uint32_t* tiles_touched, const float* partials, const uint32_t* state,
                                   int32_t N, float* g_positions, float* g_scales, float* g_rotations, float* g_opacity,
                                   float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials,
-                                  void* stream)
+                                  const uint64_t* vis, void* stream)
 {
     if (N <= 0) return GSX_E_INVALID;
     if (!positions || !scales || !rotations || !pose || !rank_of || !offsets || !tiles_touched || !partials) return GSX_E_INVALID;
@@ -462,7 +522,7 @@ int gsx::preprocess_bwd_with_loss(const float* positions, const float* scales, c
     preprocess_bwd_kernel<<<dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         positions, scales, rotations, pose, rank_of, offsets, tiles_touched, partials, state,
         nullptr, nullptr, nullptr, N, 0, g_positions, g_scales, g_rotations, g_opacity, g_features, loss_partials, (long long)loss_n, loss,
-        norm_partials);
+        norm_partials, vis);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -105,6 +105,22 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              0, stream);
 }
 
+#ifndef GSX_VIEW_VIS
+#define GSX_VIEW_VIS 1
+#endif
+// The one-call trainer step marks the Gaussians whose footprint misses the image while it projects them (one bit each): the records
+// stage then neither gathers their packed rows nor writes their records nor their rank_of entries (a random 4-byte store each), and
+// the backward asks the bitmap before it looks up a rank.  Nothing reads the record of a splat without instances; the public stage
+// calls and gsx_view_forward keep writing every rank's.  The bitmap lives where the sorted tile ids would (which the one-call step
+// does not write, gsx.h): images of up to 8192 tiles (the one-pass tile sorts; they also have the packed tile boxes, so that the
+// emit pass does not need the records' boxes), and a block whose capacity leaves room for N bits there.
+static uint64_t* step_vis(const Layout& L, char* arena, int32_t N, int32_t H, int32_t W, int64_t capacity)
+{
+    const int64_t tiles = (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE);
+    if (!GSX_VIEW_VIS || N <= 0 || tiles > 8192 || L.off[GSX_VIEW_TILE_BOX] < 0 || 4 * capacity < 8 * (((int64_t)N + 63) / 64)) return nullptr;
+    return reinterpret_cast<uint64_t*>(arena + L.off[GSX_VIEW_TILES_SORTED]);
+}
+
 static int view_forward_impl(const float* positions, const float* scales, const float* rotations,
                              const float* opacity, const float* features, const float* pose,
                              int32_t N, int32_t H, int32_t W, int64_t capacity, int32_t depth_bits,
@@ -127,8 +143,9 @@ static int view_forward_impl(const float* positions, const float* scales, const 
     auto raw = [&](int slot) { return static_cast<void*>(at(slot)); };
     uint64_t* total = u64(GSX_VIEW_TOTAL);
 
-    st = gsx_project_fwd(positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d,
-                         u32(GSX_VIEW_DEPTH_KEYS), f32(GSX_VIEW_PRE), stream);
+    uint64_t* vis = late ? step_vis(L, static_cast<char*>(arena), N, H, W, capacity) : nullptr;
+    st = gsx::project_fwd_impl(positions, scales, rotations, opacity, features, pose, N, mean2d, depth, cov2d,
+                               u32(GSX_VIEW_DEPTH_KEYS), f32(GSX_VIEW_PRE), H, W, vis, stream);
     if (st != GSX_OK) return st;
     const uint32_t* order = given_order;
     if (!order) {
@@ -140,8 +157,8 @@ static int view_forward_impl(const float* positions, const float* scales, const 
         if (st != GSX_OK) return st;
         order = u32(GSX_VIEW_ORDER);
     }
-    st = gsx_build_records(f32(GSX_VIEW_PRE), order, N, H, W, f32(GSX_VIEW_REC), u32(GSX_VIEW_TILES_TOUCHED), u32(GSX_VIEW_RANK_OF),
-                           u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_TILE_BOX), stream);
+    st = gsx::build_records_impl(f32(GSX_VIEW_PRE), order, N, H, W, f32(GSX_VIEW_REC), u32(GSX_VIEW_TILES_TOUCHED), u32(GSX_VIEW_RANK_OF),
+                                 u64(GSX_VIEW_TT_BLOCK_SUMS), u32(GSX_VIEW_TILE_BOX), vis, stream);
     if (st != GSX_OK) return st;
     // The scan of the tile counts rides in the emit kernel (one dependent launch less) when the instance count can reach the host
     // from that kernel: pinned words the device can address (what torch's pin_memory() gives), or nobody asking for it.
@@ -265,7 +282,7 @@ static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void*
                                     u32(GSX_VIEW_TILES_TOUCHED), partials, s->state, s->N,
                                     s->grad[0], s->grad[1], s->grad[2], s->grad[3], s->grad[4],
                                     fold_loss ? static_cast<const double*>(s->loss_ws) : nullptr, px, fold_loss ? s->loss : nullptr,
-                                    norm_partials, stream);
+                                    norm_partials, step_vis(L, arena, s->N, s->H, s->W, s->capacity), stream);
 }
 
 GSX_API int gsx_train_step_grads(const gsx_step* s, void* stream) { return train_step_grads_impl(s, nullptr, stream); }

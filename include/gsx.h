@@ -313,9 +313,12 @@ int gsx_l1_ssim_bwd(const float* pred, const float* target, int32_t planes, int3
  * same `step`.  GSX_OK: the step is enqueued whole.  The third word is why the event sits where it does: the tile sort writes
  * 1 + the number of EMPTY tiles there (images of up to 4096 tiles), and a view that leaves a tile empty cannot take the
  * reference's global early exit (that tile's pixels stay at alpha 0) -- gsx_composite_fwd's exit path, three launches that
- * would find nothing to do, is then not enqueued at all.  Same results either way.  One buffer of the block differs from
- * gsx_view_forward's: GSX_VIEW_TILES_SORTED is left unwritten for images of up to 8192 tiles (nothing behind the tile sort reads the
- * sorted tile ids -- compositing and the backward go by the ranges and the sorted ranks; gsx_view_forward itself always writes them).
+ * would find nothing to do, is then not enqueued at all.  Same results either way.  For images of up to 8192 tiles three buffers of the
+ * block differ from gsx_view_forward's: GSX_VIEW_TILES_SORTED does not hold the sorted tile ids (nothing behind the tile sort reads them
+ * -- compositing and the backward go by the ranges and the sorted ranks) but, in its first N / 8 bytes, one bit per GAUSSIAN: set when
+ * its footprint touches the image (written by the projection kernel); and GSX_VIEW_REC / GSX_VIEW_RANK_OF are written for those
+ * Gaussians only (a splat without instances has no reader for its record, and the backward asks the bitmap before it looks up a rank).
+ * gsx_view_forward itself always writes all of them.
  * gsx_train_step_grads / gsx_train_step_apply are the step's two halves, for data-parallel ranks (the reference wraps the
  * model in DistributedDataParallel, scripts/train.py:134-139: the gradient average sits between backward and
  * clip_grad_norm_, training/trainer.py:166-175): _grads enqueues everything up to the gradients (forward, criterion,
