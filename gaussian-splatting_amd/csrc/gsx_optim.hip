@@ -128,14 +128,23 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs a, const double* 
         const long long j = (q - a.qbegin[t]) * 4, n = a.begin[t + 1] - a.begin[t];
         const float ns = a.neg_step_size[t];
         if (a.vec[t] && j + 4 <= n) {
-            float4 p = *reinterpret_cast<float4*>(a.p[t] + j), g = *reinterpret_cast<float4*>(a.g[t] + j);
-            float4 m = *reinterpret_cast<float4*>(a.m[t] + j), v = *reinterpret_cast<float4*>(a.v[t] + j);
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            // Streaming loads and stores for what nothing reads again before the next step's optimizer -- the two moments, and the gradient
+            // unless it is written back: 280 of the kernel's 390 MB no longer push the parameters (the projection reads them next), the
+            // packed rows and the records out of the caches.  One A/B on one box: step 0.686 -> 0.668 ms (this kernel 72 -> 68.5 us,
+            // the records stage behind it 44 -> 40.5).
+            float4 p = *reinterpret_cast<float4*>(a.p[t] + j), g;
+            if (!(clip && write_clipped_grad)) { const f4 g_ = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g[t] + j)); g = make_float4(g_.x, g_.y, g_.z, g_.w); }
+            else g = *reinterpret_cast<float4*>(a.g[t] + j);
+            const f4 m_ = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.m[t] + j)), v_ = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.v[t] + j));
+            float4 m = make_float4(m_.x, m_.y, m_.z, m_.w), v = make_float4(v_.x, v_.y, v_.z, v_.w);
             adam_one(p.x, g.x, m.x, v.x, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
             adam_one(p.y, g.y, m.y, v.y, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
             adam_one(p.z, g.z, m.z, v.z, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
             adam_one(p.w, g.w, m.w, v.w, clip, coef, w1, w2, beta2, eps, bc2_sqrt, ns);
-            *reinterpret_cast<float4*>(a.p[t] + j) = p; *reinterpret_cast<float4*>(a.m[t] + j) = m;
-            *reinterpret_cast<float4*>(a.v[t] + j) = v;
+            *reinterpret_cast<float4*>(a.p[t] + j) = p;
+            __builtin_nontemporal_store(f4{m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.m[t] + j));
+            __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(a.v[t] + j));
             if (clip && write_clipped_grad) *reinterpret_cast<float4*>(a.g[t] + j) = g;
         } else {
             for (int k = 0; k < 4 && j + k < n; k++) {

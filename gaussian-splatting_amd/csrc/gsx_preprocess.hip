@@ -136,9 +136,12 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(const float* __rest
     const float q[4] = { qv.x, qv.y, qv.z, qv.w };
     Proj o; project_one(p, s, q, M, o);
     if (mean2d) {       // the reference's returned tensors: a caller that never looks at them (a trainer step with an image-only criterion) passes none
-        reinterpret_cast<float2*>(mean2d)[i] = make_float2(o.mx, o.my);
-        depth[i] = o.depth;
-        reinterpret_cast<float4*>(cov2d)[i] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
+        // (streaming stores: nothing in the view reads these 28 bytes per Gaussian back)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f2{o.mx, o.my}, reinterpret_cast<f2*>(mean2d) + i);
+        __builtin_nontemporal_store(o.depth, depth + i);
+        __builtin_nontemporal_store(f4{o.cov[0], o.cov[1], o.cov[2], o.cov[3]}, reinterpret_cast<f4*>(cov2d) + i);
     }
     key[i] = depth_key(o.depth);
     const float op = opacity[i];
