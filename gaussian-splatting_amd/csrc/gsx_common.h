@@ -92,6 +92,31 @@ int preprocess_bwd_with_loss(const float* positions, const float* scales, const 
                              float* g_features, const double* loss_partials, int64_t loss_n, float* loss, double* norm_partials,
                              const uint64_t* vis /* nullable: project_fwd_impl's bitmap; rank_of then holds visible Gaussians only */, void* stream);
 #ifdef __HIPCC__
+// (gsx_loss.hip's terms; the backward of the one-call trainer step evaluates them itself)
+constexpr float kClampLo = 1e-8f, kClampHi = 1.0f - 1e-8f;     // the reference's fp32 constants (1 - 1e-8 == 1.0f)
+
+template <int KIND>
+__device__ __forceinline__ float loss_term(float p, float t)
+{
+    if (KIND == GSX_LOSS_L1) return fabsf(p - t);
+    const float c = fminf(fmaxf(p, kClampLo), kClampHi);
+    const float d = c - t;
+    return d * d;
+}
+
+template <int KIND>
+__device__ __forceinline__ float loss_grad(float p, float t, float g_over_n)
+{
+    if (KIND == GSX_LOSS_L1) {
+        const float d = p - t;                              // abs backward: grad * sign(d), sign(0) = 0
+        return d > 0.0f ? g_over_n : (d < 0.0f ? -g_over_n : 0.0f);
+    }
+    // clamp passes the gradient on [lo, hi] inclusive; mse backward = 2 (c - t) g / n
+    const float c = fminf(fmaxf(p, kClampLo), kClampHi);
+    const bool pass = p >= kClampLo && p <= kClampHi;
+    return pass ? (2.0f * g_over_n) * (c - t) : 0.0f;
+}
+
 // (gsx_sort.hip's scans and the emit kernel's)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
@@ -119,6 +144,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_
 }
 #endif
 
+// gsx_composite_bwd with the one-call trainer step's criterion inside its launch: kind = GSX_LOSS_L1 or GSX_LOSS_CLAMPED_MSE of pred
+// (the view's rgb) against target, n elements, unit upstream gradient (g_over_n = 1 / n); partials = kLossBlocks doubles, the slices
+// and bits of gsx_loss.hip's loss_partial_kernel; vec = both images 16-byte aligned
+struct LossInBwd { const float* pred; const float* target; double* partials; long long n; int kind; int vec; float g_over_n; };
+int composite_bwd_impl(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                       const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                       int64_t max_chunks, const float* chunk_state, const uint32_t* state,
+                       const float* d_rgb, float* partials, int64_t n_rows, const LossInBwd* lw, void* stream);
 // gsx_project_fwd / gsx_build_records with the visibility bitmap of the one-call trainer step (vis: one bit per Gaussian, N / 64 words
 // rounded up; H, W: the image the footprints are cut against).  vis == nullptr: the public entry points' behaviour
 int project_fwd_impl(const float* positions, const float* scales, const float* rotations,

@@ -1536,14 +1536,55 @@ __device__ __forceinline__ void stage_sums(uint32_t lds_byte_base, float r0, flo
 }
 static_assert(kRedRow * 4 == 272, "the offsets in stage_sums are rows of kRedRow floats");
 
+// One slice of the image loss's partial sums (gsx_loss.hip: loss_partial_kernel, kLossBlocks slices, 256 threads each) by ONE wave,
+// which plays the slice's four waves one after the other: the same elements per thread, the same order of additions, the same bits.
+template <int KIND>
+__device__ __forceinline__ void loss_slice_wave(const LossInBwd& lw, int slice)
+{
+    const long long n4 = lw.n >> 2;
+    const long long per = (n4 + kLossBlocks - 1) / kLossBlocks;
+    const long long lo = (long long)slice * per, hi = min(lo + per, n4);
+    const float4* p4 = reinterpret_cast<const float4*>(lw.pred);
+    const float4* t4 = reinterpret_cast<const float4*>(lw.target);
+    double sw[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int t = w * 64 + (int)threadIdx.x;            // the slice's thread this lane plays now
+        float s = 0.0f;
+        for (long long q = lo + t; q < hi; q += kBlock) {
+            float4 p, tg;
+            if (lw.vec) { p = p4[q]; tg = t4[q]; }
+            else {
+                p = make_float4(lw.pred[4*q], lw.pred[4*q+1], lw.pred[4*q+2], lw.pred[4*q+3]);
+                tg = make_float4(lw.target[4*q], lw.target[4*q+1], lw.target[4*q+2], lw.target[4*q+3]);
+            }
+            s += (loss_term<KIND>(p.x, tg.x) + loss_term<KIND>(p.y, tg.y)) + (loss_term<KIND>(p.z, tg.z) + loss_term<KIND>(p.w, tg.w));
+        }
+        if (slice == 0 && t < (int)(lw.n & 3)) s += loss_term<KIND>(lw.pred[n4 * 4 + t], lw.target[n4 * 4 + t]);
+        double sd = (double)s;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sd += __shfl_down(sd, d, 64);
+        sw[w] = sd;
+    }
+    if (threadIdx.x == 0) lw.partials[slice] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
 __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ offsets, int n_tiles,
     uint32_t N, int H, int W, int tw, float stepx, float stepy, const uint32_t* __restrict__ state,
     const float* __restrict__ chunk_state, const uint32_t* __restrict__ chunk_meta, const uint32_t* __restrict__ chunk_dark,
     const uint32_t* __restrict__ work, const float* __restrict__ d_rgb, float* __restrict__ partials, int prezeroed,
-    uint32_t max_chunks, const float* __restrict__ mid_state, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ chunk_tile)
+    uint32_t max_chunks, const float* __restrict__ mid_state, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ chunk_tile,
+    LossInBwd lw)
 {
+    // the one-call trainer step's criterion (L1 or clamped MSE against lw.target, unit upstream gradient) rides in this launch: the
+    // grid's last kLossBlocks workgroups leave the loss's partial sums, and every work item forms dL/d(rgb) from the image itself
+    if (lw.target && blockIdx.x >= gridDim.x - (uint32_t)kLossBlocks) {
+        if (lw.kind == GSX_LOSS_L1) loss_slice_wave<GSX_LOSS_L1>(lw, (int)(blockIdx.x - (gridDim.x - (uint32_t)kLossBlocks)));
+        else loss_slice_wave<GSX_LOSS_CLAMPED_MSE>(lw, (int)(blockIdx.x - (gridDim.x - (uint32_t)kLossBlocks)));
+        return;
+    }
     __shared__ float4 s_a[kCBatch], s_b[kCBatch];
     __shared__ float s_cx[kCBatch];
     __shared__ uint32_t s_slot[kCBatch];
@@ -1624,7 +1665,18 @@ __global__ __launch_bounds__(64) void chunk_bwd_kernel(
     for (int k = 0; k < 4; k++) {
         const int x = x0 + ((k & 1) << 3), y = y0 + ((k >> 1) << 3);
         G0[k] = G1[k] = G2[k] = 0.f;
-        if (x < W && y < H) { const size_t p = (size_t)y * W + x; G0[k] = d_rgb[p]; G1[k] = d_rgb[P + p]; G2[k] = d_rgb[2*P + p]; }
+        if (x < W && y < H) {
+            const size_t p = (size_t)y * W + x;
+            if (lw.target) {          // what loss_partial_grad_kernel would have left in d_rgb (unit upstream gradient)
+                if (lw.kind == GSX_LOSS_L1) {
+                    G0[k] = loss_grad<GSX_LOSS_L1>(lw.pred[p], lw.target[p], lw.g_over_n); G1[k] = loss_grad<GSX_LOSS_L1>(lw.pred[P + p], lw.target[P + p], lw.g_over_n);
+                    G2[k] = loss_grad<GSX_LOSS_L1>(lw.pred[2*P + p], lw.target[2*P + p], lw.g_over_n);
+                } else {
+                    G0[k] = loss_grad<GSX_LOSS_CLAMPED_MSE>(lw.pred[p], lw.target[p], lw.g_over_n); G1[k] = loss_grad<GSX_LOSS_CLAMPED_MSE>(lw.pred[P + p], lw.target[P + p], lw.g_over_n);
+                    G2[k] = loss_grad<GSX_LOSS_CLAMPED_MSE>(lw.pred[2*P + p], lw.target[2*P + p], lw.g_over_n);
+                }
+            } else { G0[k] = d_rgb[p]; G1[k] = d_rgb[P + p]; G2[k] = d_rgb[2*P + p]; }
+        }
         const int pix = k * 64 + lane;
         const float* cs = chunk_state + (size_t)chunk * GSX_STATE_WORDS * kPixPerTile + pix;
         float b0 = cs[0 * kPixPerTile], b1 = cs[1 * kPixPerTile], b2 = cs[2 * kPixPerTile];      // colour behind the chunk
@@ -1834,9 +1886,20 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
                               int64_t max_chunks, const float* chunk_state, const uint32_t* state,
                               const float* d_rgb, float* partials, int64_t n_rows, void* stream)
 {
+    return gsx::composite_bwd_impl(rec, ranks_sorted, ranges, chunk_base, offsets, N, H, W, max_chunks, chunk_state, state, d_rgb, partials, n_rows,
+                                   nullptr, stream);
+}
+
+// lw (nullable; N > 0 and max_chunks > 0): the criterion inside the launch (LossInBwd, gsx_common.h); d_rgb is then not read
+int gsx::composite_bwd_impl(const float* rec, const uint32_t* ranks_sorted, const uint32_t* ranges,
+                            const uint32_t* chunk_base, const uint32_t* offsets, int32_t N, int32_t H, int32_t W,
+                            int64_t max_chunks, const float* chunk_state, const uint32_t* state,
+                            const float* d_rgb, float* partials, int64_t n_rows, const LossInBwd* lw, void* stream)
+{
     if (N < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || max_chunks < 0) return GSX_E_INVALID;
+    if (lw && (N == 0 || max_chunks == 0 || !lw->pred || !lw->target || !lw->partials || lw->n <= 0)) return GSX_E_INVALID;
     if (N == 0 || max_chunks == 0) return GSX_OK;
-    if (!rec || !ranks_sorted || !ranges || !chunk_base || !offsets || !chunk_state || !state || !d_rgb || !partials) return GSX_E_INVALID;
+    if (!rec || !ranks_sorted || !ranges || !chunk_base || !offsets || !chunk_state || !state || (!d_rgb && !lw) || !partials) return GSX_E_INVALID;
     if (max_chunks > (int64_t)kItemChunk) return GSX_E_RANGE;
     if ((uintptr_t)rec & 15u) return GSX_E_INVALID;
     if (n_rows < 0) return GSX_E_INVALID;
@@ -1850,11 +1913,13 @@ GSX_API int gsx_composite_bwd(const float* rec, const uint32_t* ranks_sorted, co
     const uint32_t* meta = reinterpret_cast<const uint32_t*>(chunk_state + (size_t)max_chunks * GSX_STATE_WORDS * kPixPerTile);
     // one workgroup per work item: a chunk, or -- in a shallow view -- half a chunk (at most kDeepChunks - 1 chunks are cut)
     const int64_t grid = max_chunks + (max_chunks < (int64_t)kDeepChunks ? max_chunks : (int64_t)kDeepChunks);
-    chunk_bwd_kernel<<<dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream>>>(
+    LossInBwd none = {};
+    chunk_bwd_kernel<<<dim3((unsigned)(grid + (lw ? kLossBlocks : 0))), dim3(64), 0, (hipStream_t)stream>>>(
         (const float4*)rec, ranks_sorted, ranges, chunk_base, offsets, tw * th, (uint32_t)N, H, W, tw,
         lin_step(W), lin_step(H), state, chunk_state, meta, meta + max_chunks, meta + 2 * (size_t)max_chunks,
         d_rgb, partials, prezeroed, (uint32_t)max_chunks, reinterpret_cast<const float*>(meta + tail_mid_offset((size_t)max_chunks)),
-        reinterpret_cast<const uint8_t*>(meta + tail_pay_offset((size_t)max_chunks)), meta + tail_hdr_offset((size_t)max_chunks));
+        reinterpret_cast<const uint8_t*>(meta + tail_pay_offset((size_t)max_chunks)), meta + tail_hdr_offset((size_t)max_chunks),
+        lw ? *lw : none);
     GSX_LAUNCH_CHECK();
     return GSX_OK;
 }

@@ -10,17 +10,6 @@
 
 namespace gsx {
 
-constexpr float kClampLo = 1e-8f, kClampHi = 1.0f - 1e-8f;     // the reference's fp32 constants (1 - 1e-8 == 1.0f)
-
-template <int KIND>
-__device__ __forceinline__ float loss_term(float p, float t)
-{
-    if (KIND == GSX_LOSS_L1) return fabsf(p - t);
-    const float c = fminf(fmaxf(p, kClampLo), kClampHi);
-    const float d = c - t;
-    return d * d;
-}
-
 template <int KIND, bool VEC>
 __global__ __launch_bounds__(kBlock) void loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                               long long n, double* __restrict__ partials)
@@ -48,19 +37,6 @@ __global__ __launch_bounds__(kBlock) void loss_partial_kernel(const float* __res
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sd;
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
-
-template <int KIND>
-__device__ __forceinline__ float loss_grad(float p, float t, float g_over_n)
-{
-    if (KIND == GSX_LOSS_L1) {
-        const float d = p - t;                              // abs backward: grad * sign(d), sign(0) = 0
-        return d > 0.0f ? g_over_n : (d < 0.0f ? -g_over_n : 0.0f);
-    }
-    // clamp passes the gradient on [lo, hi] inclusive; mse backward = 2 (c - t) g / n
-    const float c = fminf(fmaxf(p, kClampLo), kClampHi);
-    const bool pass = p >= kClampLo && p <= kClampHi;
-    return pass ? (2.0f * g_over_n) * (c - t) : 0.0f;
 }
 
 // forward and gradient in ONE pass, for the common case that the loss is the root of the backward (upstream = 1): the

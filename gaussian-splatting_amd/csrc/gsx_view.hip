@@ -263,19 +263,28 @@ static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void*
         if (st != GSX_OK) return st;
     }
     const int64_t px = 3ll * s->H * s->W;
+#ifndef GSX_LOSS_IN_BWD
+#define GSX_LOSS_IN_BWD 1
+#endif
+    const bool loss_in_bwd = GSX_LOSS_IN_BWD && s->loss_kind != GSX_LOSS_L1_SSIM && s->N > 0 && L.max_chunks > 0 &&
+                             s->loss_ws_bytes >= (size_t)gsx::kLossBlocks * 8;
     if (s->loss_kind == GSX_LOSS_L1_SSIM) {
         st = gsx_l1_ssim_fwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, s->loss, s->loss_ws, s->loss_ws_bytes, stream);
         if (st != GSX_OK) return st;
         st = gsx_l1_ssim_bwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, nullptr, s->loss_ws, s->loss_ws_bytes, s->d_rgb, stream);
-    } else {
+    } else if (!loss_in_bwd) {
         // (the loss VALUE is reduced by the last kernel of this half: preprocess_bwd_with_loss)
         st = gsx::image_loss_fwd_grad_partials(s->loss_kind, s->rgb, s->target, px, s->d_rgb, s->loss_ws, s->loss_ws_bytes, stream);
     }
     if (st != GSX_OK) return st;
     float* partials = reinterpret_cast<float*>(arena + L.off[GSX_VIEW_PARTIALS]);
-    st = gsx_composite_bwd(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), u32(GSX_VIEW_OFFSETS),
-                           s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,
-                           s->d_rgb, partials, D, stream);
+    // L1 / clamped MSE: no launch of its own for the criterion -- the backward forms dL/d(rgb) from the image and the target itself and
+    // its grid's last workgroups leave the loss's partial sums (the same slices, the same bits: gsx_composite.hip, loss_slice_wave)
+    const gsx::LossInBwd lw = { s->rgb, s->target, static_cast<double*>(s->loss_ws), (long long)px, s->loss_kind,
+                                ((((uintptr_t)s->rgb | (uintptr_t)s->target) & 15u) == 0) ? 1 : 0, 1.0f / (float)px };
+    st = gsx::composite_bwd_impl(rec, u32(GSX_VIEW_RANKS_SORTED), u32(GSX_VIEW_RANGES), u32(GSX_VIEW_CHUNK_BASE), u32(GSX_VIEW_OFFSETS),
+                                 s->N, s->H, s->W, L.max_chunks, reinterpret_cast<const float*>(arena + L.off[GSX_VIEW_CHUNK_STATE]), s->state,
+                                 s->d_rgb, partials, D, loss_in_bwd ? &lw : nullptr, stream);
     if (st != GSX_OK) return st;
     const bool fold_loss = s->loss_kind != GSX_LOSS_L1_SSIM;
     return gsx::preprocess_bwd_with_loss(s->param[0], s->param[1], s->param[2], s->pose, u32(GSX_VIEW_RANK_OF), u32(GSX_VIEW_OFFSETS),

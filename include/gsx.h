@@ -352,7 +352,8 @@ typedef struct gsx_step {
     float* mean2d; float* depth; float* cov2d;     /* the reference's returned tensors; all three NULL = not wanted */
     float* rgb; float* alpha;
     uint32_t* state;               /* 4 x u32, as gsx_composite_fwd */
-    float* d_rgb;                  /* 3 x H x W floats of scratch: dLoss/drgb */
+    float* d_rgb;                  /* 3 x H x W floats of scratch: dLoss/drgb (written for GSX_LOSS_L1_SSIM only: the other criteria's
+                                    * gradient is formed inside the compositing backward) */
     float* loss;                   /* 3 floats: [0] the criterion; GSX_LOSS_L1_SSIM also writes [1] = L1, [2] = SSIM */
     void* loss_ws; size_t loss_ws_bytes;   /* gsx_image_loss_workspace_bytes() or gsx_l1_ssim_workspace_bytes(3, H, W) */
     void* adam_ws; size_t adam_ws_bytes;   /* gsx_clip_adam_workspace_bytes() (+ 8 * ceil(N / 256), see above) */
