@@ -105,9 +105,6 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
                              0, stream);
 }
 
-#ifndef GSX_VIEW_VIS
-#define GSX_VIEW_VIS 1
-#endif
 // The one-call trainer step marks the Gaussians whose footprint misses the image while it projects them (one bit each): the records
 // stage then neither gathers their packed rows nor writes their records nor their rank_of entries (a random 4-byte store each), and
 // the backward asks the bitmap before it looks up a rank.  Nothing reads the record of a splat without instances; the public stage
@@ -117,7 +114,7 @@ GSX_API int gsx_view_forward(const float* positions, const float* scales, const 
 static uint64_t* step_vis(const Layout& L, char* arena, int32_t N, int32_t H, int32_t W, int64_t capacity)
 {
     const int64_t tiles = (int64_t)((W + GSX_TILE - 1) / GSX_TILE) * ((H + GSX_TILE - 1) / GSX_TILE);
-    if (!GSX_VIEW_VIS || N <= 0 || tiles > 8192 || L.off[GSX_VIEW_TILE_BOX] < 0 || 4 * capacity < 8 * (((int64_t)N + 63) / 64)) return nullptr;
+    if (N <= 0 || tiles > 8192 || L.off[GSX_VIEW_TILE_BOX] < 0 || 4 * capacity < 8 * (((int64_t)N + 63) / 64)) return nullptr;
     return reinterpret_cast<uint64_t*>(arena + L.off[GSX_VIEW_TILES_SORTED]);
 }
 
@@ -263,10 +260,7 @@ static int train_step_grads_impl(const gsx_step* s, double* norm_partials, void*
         if (st != GSX_OK) return st;
     }
     const int64_t px = 3ll * s->H * s->W;
-#ifndef GSX_LOSS_IN_BWD
-#define GSX_LOSS_IN_BWD 1
-#endif
-    const bool loss_in_bwd = GSX_LOSS_IN_BWD && s->loss_kind != GSX_LOSS_L1_SSIM && s->N > 0 && L.max_chunks > 0 &&
+    const bool loss_in_bwd = s->loss_kind != GSX_LOSS_L1_SSIM && s->N > 0 && L.max_chunks > 0 &&
                              s->loss_ws_bytes >= (size_t)gsx::kLossBlocks * 8;
     if (s->loss_kind == GSX_LOSS_L1_SSIM) {
         st = gsx_l1_ssim_fwd(s->rgb, s->target, 3, s->H, s->W, s->lambda_dssim, s->loss, s->loss_ws, s->loss_ws_bytes, stream);
