@@ -1393,6 +1393,17 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     __shared__ uint32_t s_rank[kBlock];
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_k, s_quit;
+    // Checkpoints of a non-monotone view's rounds: where the walk of the workgroup's j-th tile stood at the START of the last batch it
+    // took (position in the list, A of every pixel there).  k only grows, and every instance in front of that batch has a rank below
+    // the round's new k (the batch was walked because a pixel found its rank in it, or met the first rank above the old k in it), so
+    // the next round resumes there with the very A the walk from the list's head would arrive with -- the rounds together are ONE
+    // pass over the lists instead of one each.  Tiles beyond the kSatCk-th of a workgroup are walked from their head as before.
+    // Eight slots (every tile of an image of up to 4096 tiles): with them the kernel's LDS is 17.8 KB, i.e. eight workgroups per CU
+    // -- the four searches of kSatBlocks workgroups that may spin side by side (above) still all fit the chip.
+    constexpr int kSatCk = 8;
+    static_assert((size_t)kSatCk * kBlock * 4 + 2 * kBlock * 16 + kBlock * 4 + 256 <= 160 * 1024 / 8, "eight searching workgroups per CU");
+    __shared__ float s_ck_a[kSatCk][kBlock];
+    __shared__ uint32_t s_ck_pos[kSatCk];
     const uint32_t flags = state[1];          // (uniform over the grid: written by pass 0's combine launch)
     if (flags & 1u) {                        // some pixel never saturates: no early exit
         if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = GSX_RANK_NONE;
@@ -1413,7 +1424,10 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // the end in ONE workgroup (17 k splats, 1.4 ms on the bench scene after 1200 steps: the trainer step had doubled), while
         // a sparse tile at the image's edge answers in microseconds.  Everybody still arrives at the barrier below.
         bool quit = false;
+        int slot = -1;
         for (int ti = blockIdx.x; ti < n_tiles && !quit; ti += n_blocks) {
+            slot++;
+            const bool ck = !monotone && slot < kSatCk;
             // (a stride walk over the tiles: with the identity map the first tiles of all workgroups are the image's top rows -- on
             // the bench orbit the dense band itself, so that the first sparse tile, the one with the pixel that never saturates,
             // only came up in the second round of tiles, 60 us into the search)
@@ -1425,34 +1439,53 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             float A = 0.f;
             uint32_t f = inside ? GSX_RANK_NONE : k_cur;      // pixels outside the image do not vote
             bool looked = false;                              // has the state AT k_cur been looked at
-            for (uint32_t start = begin; start < end; start += kBlock) {
+            uint32_t start0 = begin;
+            if (ck && round > 1u && begin < end) { start0 = s_ck_pos[slot]; A = s_ck_a[slot][threadIdx.x]; }       // (own words / read behind barriers)
+            // the next batch's records travel while this one is walked (rank, then record: two dependent round trips that every batch
+            // of 256 splats used to wait for)
+            uint32_t nr = 0u; float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            auto fetch = [&](uint32_t at) {
+                const uint32_t i = at + threadIdx.x;
+                if (i < end) { nr = ranks[i]; const float4* R = rec + (size_t)kRecVec * nr; na = R[0]; nb = R[1]; }
+            };
+            fetch(start0);
+            for (uint32_t start = start0; start < end; start += kBlock) {
+                if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
                 uint32_t seen = 0u;                           // thread 0: the word as loaded one look ago (the load's latency runs under 32 splats)
                 if (!monotone && threadIdx.x == 0) { seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_quit = seen; }
-                const uint32_t i = start + threadIdx.x;
-                if (i < end) {
-                    const uint32_t r = ranks[i];
-                    s_rank[threadIdx.x] = r;
-                    const float4* R = rec + (size_t)kRecVec * r;
-                    s_a[threadIdx.x] = R[0]; s_b[threadIdx.x] = R[1];
-                }
+                if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
                 __syncthreads();
+                fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
-                for (uint32_t j = 0; j < cnt; j++) {
-                    if (!monotone && (j & 31u) == 31u) {      // every 32 splats: has somebody found a pixel that never gets there?
+                // four splats at a time: their records and alphas first (twelve LDS reads and four exponentials in flight), then the four
+                // dependent steps of A -- the walk of a deep tile is ONE workgroup's chain, and taken one splat at a time every step
+                // waited for its own LDS reads
+                for (uint32_t j = 0; j < cnt; j += 4u) {
+                    if (!monotone && (j & 31u) == 28u) {      // every 32 splats: has somebody found a pixel that never gets there?
                         if (threadIdx.x == 0) {
                             __hip_atomic_store(&s_quit, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         if (__hip_atomic_load(&s_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GSX_RANK_NONE) break;   // (each wave for itself)
                     }
-                    const uint32_t r = s_rank[j];
-                    if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
-                    const float4 a = s_a[j], b = s_b[j];
-                    const float dx = gx - a.x, dy = gy - a.y;
-                    const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                    const float am = b.y * __builtin_amdgcn_exp2f(q);
-                    A = A + (1.0f - A) * am;
-                    if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
+                    uint32_t rr[4]; float am[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {             // (entries past cnt are stale but inside the arrays: j + 3 < kBlock)
+                        rr[u] = s_rank[j + u];
+                        const float4 a = s_a[j + u], b = s_b[j + u];
+                        const float dx = gx - a.x, dy = gy - a.y;
+                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                        am[u] = b.y * __builtin_amdgcn_exp2f(q);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (j + u < cnt) {                    // (uniform)
+                            const uint32_t r = rr[u];
+                            if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
+                            A = A + (1.0f - A) * am[u];
+                            if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
+                        }
+                    }
                 }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
                 // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)

@@ -12,7 +12,7 @@ m = GaussianSplat(n); m.load_state_dict({k: torch.from_numpy(v) for k, v in para
 opt = make_optimizer(m, fused_clip_norm=0.1)
 poses = torch.from_numpy(create_orbit_poses(4.0, 60, 45.0)).to(dev)
 target = torch.rand(1, 3, H, W, device=dev)
-for s in range(900):
+for s in range(int(sys.argv[1]) if len(sys.argv) > 1 else 900):
     train_step(m, opt, poses[s % 60:s % 60 + 1], target, l1_loss, 0.1)
 torch.cuda.synchronize()
 with torch.no_grad():
