@@ -1387,10 +1387,16 @@ constexpr int kSatBlocks = 512;           // workgroups that take part in the ro
                                           // resident (8 of these per CU), so that up to four streams' searches can spin side by side
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
-    int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state)
+    int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
+    const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks)
 {
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
+    // which of the batch's 256 splats reach which 8x8 quadrant of the tile: [staging wave][quadrant] -> 64 bits.  Wave w walks
+    // quadrant w and only the splats that reach it -- the masks are the chunk pass's (a shallow view leaves one byte per instance in
+    // its chunks' payload words); what they drop is what the footprint cut drops from the tile lists themselves: pairs below the cut.
+    // A trained bench scene's walk takes 1.5 of a splat's 4 quadrants on average.  Without masks (deep views) every splat is taken.
+    __shared__ unsigned long long s_sets[4][4];
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_k, s_quit;
     // Checkpoints of a non-monotone view's rounds: where the walk of the workgroup's j-th tile stood at the START of the last batch it
@@ -1412,6 +1418,10 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     // A view without a non-monotone splat needs ONE pass and no barrier: every workgroup adds its maximum to state[0]
     // (zeroed by pass 0) and is done.  Otherwise the rounds below, on the first kSatBlocks workgroups only.
     const bool monotone = (flags & 2u) == 0u;
+    const bool use_masks = masks != nullptr && chunk_base[n_tiles] < kDeepChunks;
+    const uint32_t ch_mask = chunk_base[n_tiles + 1] - 1u;              // chunk size (64, 128 or 256) - 1
+    const int ch_shift = 31 - __builtin_clz(chunk_base[n_tiles + 1]);
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
     const uint32_t n_blocks = monotone ? gridDim.x : min(gridDim.x, (uint32_t)kSatBlocks);
     if (blockIdx.x >= n_blocks) return;
     uint32_t k_cur = 0u, result;
@@ -1433,8 +1443,9 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // only came up in the second round of tiles, 60 us into the search)
             const int tile = (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles);
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
-            const int x = (tile % tw) * GSX_TILE + (threadIdx.x & 15), y = (tile / tw) * GSX_TILE + (threadIdx.x >> 4);
+            int x, y; pix_xy(wave, lane, tile % tw, tile / tw, x, y);      // (wave = quadrant)
             const bool inside = x < W && y < H;
+            const uint32_t chunk0 = chunk_base[tile];
             const float gx = pix_coord(min(x, W - 1), W, stepx), gy = pix_coord(min(y, H - 1), H, stepy);
             float A = 0.f;
             uint32_t f = inside ? GSX_RANK_NONE : k_cur;      // pixels outside the image do not vote
@@ -1443,10 +1454,15 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             if (ck && round > 1u && begin < end) { start0 = s_ck_pos[slot]; A = s_ck_a[slot][threadIdx.x]; }       // (own words / read behind barriers)
             // the next batch's records travel while this one is walked (rank, then record: two dependent round trips that every batch
             // of 256 splats used to wait for)
-            uint32_t nr = 0u; float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            uint32_t nr = 0u, nm = 0u; float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
             auto fetch = [&](uint32_t at) {
                 const uint32_t i = at + threadIdx.x;
-                if (i < end) { nr = ranks[i]; const float4* R = rec + (size_t)kRecVec * nr; na = R[0]; nb = R[1]; }
+                nm = 0u;
+                if (i < end) {
+                    nr = ranks[i]; const float4* R = rec + (size_t)kRecVec * nr; na = R[0]; nb = R[1];
+                    const uint32_t rel = i - begin;
+                    nm = use_masks ? (uint32_t)masks[(size_t)(chunk0 + (rel >> ch_shift)) * (64 * 4) + (rel & ch_mask)] : 0xFu;
+                }
             };
             fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
@@ -1454,39 +1470,39 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 uint32_t seen = 0u;                           // thread 0: the word as loaded one look ago (the load's latency runs under 32 splats)
                 if (!monotone && threadIdx.x == 0) { seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_quit = seen; }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long bset = __builtin_amdgcn_ballot_w64(((nm >> k) & 1u) != 0u);
+                    if (lane == 0) s_sets[wave][k] = bset;
+                }
                 __syncthreads();
                 fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
-                // four splats at a time: their records and alphas first (twelve LDS reads and four exponentials in flight), then the four
-                // dependent steps of A -- the walk of a deep tile is ONE workgroup's chain, and taken one splat at a time every step
-                // waited for its own LDS reads
-                for (uint32_t j = 0; j < cnt; j += 4u) {
-                    if (!monotone && (j & 31u) == 28u) {      // every 32 splats: has somebody found a pixel that never gets there?
-                        if (threadIdx.x == 0) {
-                            __hip_atomic_store(&s_quit, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t visited = 0u;
+                bool leave = false;
+                for (int seg = 0; seg < 4 && !leave; seg++) {
+                    for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
+                        const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        if (!monotone && (++visited & 31u) == 0u) {      // every 32 splats: has somebody found a pixel that never gets there?
+                            if (threadIdx.x == 0) {
+                                __hip_atomic_store(&s_quit, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            if (__hip_atomic_load(&s_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GSX_RANK_NONE) { leave = true; break; }   // (each wave for itself)
                         }
-                        if (__hip_atomic_load(&s_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GSX_RANK_NONE) break;   // (each wave for itself)
-                    }
-                    uint32_t rr[4]; float am[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {             // (entries past cnt are stale but inside the arrays: j + 3 < kBlock)
-                        rr[u] = s_rank[j + u];
-                        const float4 a = s_a[j + u], b = s_b[j + u];
+                        const uint32_t r = s_rank[j];
+                        const float4 a = s_a[j], b = s_b[j];
                         const float dx = gx - a.x, dy = gy - a.y;
                         const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                        am[u] = b.y * __builtin_amdgcn_exp2f(q);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (j + u < cnt) {                    // (uniform)
-                            const uint32_t r = rr[u];
-                            if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
-                            A = A + (1.0f - A) * am[u];
-                            if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
-                        }
+                        const float am = b.y * __builtin_amdgcn_exp2f(q);
+                        if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
+                        A = A + (1.0f - A) * am;
+                        if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
                     }
                 }
+                // (the batch went past rank k_cur without this quadrant meeting a splat behind it: A is the state AT k_cur)
+                if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
                 // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)
                 if (!monotone && __syncthreads_or(threadIdx.x == 0 && (seen == GSX_RANK_NONE || s_quit == GSX_RANK_NONE))) { quit = true; break; }
@@ -1889,12 +1905,12 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     }
     // pass 0: everything; F3: exact exit rank if every pixel saturated; pass 1: re-composite up to it
     if (depth_map) {
-        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr, need_bwd ? hdr : nullptr);
+        chunk_fwd_wg_kernel<true><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, depth_map, reinterpret_cast<uint8_t*>(pay), need_bwd ? hdr : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, true, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<true><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, true, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
     } else {
-        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr, need_bwd ? reinterpret_cast<uint8_t*>(pay) : nullptr, need_bwd ? hdr : nullptr);
+        chunk_fwd_wg_kernel<false><<<gc0l, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, H, W, tw, sx, sy, state, chunk_state, meta, work, need_bwd ? mid_state : nullptr, n_list, order_tab, rgb, alpha, nullptr, reinterpret_cast<uint8_t*>(pay), need_bwd ? hdr : nullptr);
         if (could_be_deep) chunk_fwd_kernel<false, false, true><<<gc, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, tile_dark);
         tile_combine_par_kernel<false><<<gp, dim3(kParGroups * kBlock), 0, st>>>(chunk_base, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, order_tab);
         if (could_be_deep) tile_combine_kernel<false, false, true><<<gt, dim3(kBlock), 0, st>>>(chunk_base, (uint32_t)N, H, W, tw, need_bwd, state, chunk_state, meta, meta + max_chunks, work, hdr, pay, (uint32_t)max_chunks, n_tiles, rgb, alpha, depth_map, ranges, 0);
@@ -1903,7 +1919,8 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     if (!(which & 2)) { GSX_LAUNCH_CHECK(); return GSX_OK; }
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
-    saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state);
+    saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state, chunk_base,
+                                                         max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
