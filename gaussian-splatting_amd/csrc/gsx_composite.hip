@@ -1381,15 +1381,21 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
 // workgroup arrives at every barrier, and the rounds end because k grows until it stands or some pixel reports "never");
 // a view without a non-monotone splat (state[1] bit 1 clear: the combine pass raises it from the chunks' flags) takes the
 // one pass it always took, on the whole grid, without a barrier.  state[2] = the running maximum (monotone: no reset between
-// rounds), state[3] = barrier arrivals; both zeroed with state[0..1] by pass 0.
+// rounds), zeroed with state[0..1] by pass 0; the barrier's arrivals count in the work counters' line (below), state[3] gets a copy at the end.
 // ------------------------------------------------------------------------------------------
 constexpr int kSatBlocks = 512;           // workgroups that take part in the rounds of a non-monotone view: a quarter of what the chip holds
                                           // resident (8 of these per CU), so that up to four streams' searches can spin side by side
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
-    const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks)
+    const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work)
 {
+    // The grid barrier of the rounds lives in the work counters' line (two words nothing else uses between the passes: arrivals, and a
+    // copy of "some pixel never saturates"), NOT next to state[2]: the workgroups that still walk look at state[2] every 128 splats,
+    // and with up to 511 waiting workgroups polling the same 16 bytes each of those looks took tens of microseconds -- a trained bench
+    // scene's search ran at a microsecond per splat (5 ms a view) whatever its walk cost.
+    uint32_t* const bar_arrivals = work + 14;
+    uint32_t* const bar_never = work + 15;
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
     // which of the batch's 256 splats reach which 8x8 quadrant of the tile: [staging wave][quadrant] -> 64 bits.  Wave w walks
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        if (!monotone && (++visited & 31u) == 0u) {      // every 32 splats: has somebody found a pixel that never gets there?
+                        if (!monotone && (++visited & 127u) == 0u) {     // every 128 splats: has somebody found a pixel that never gets there?
                             if (threadIdx.x == 0) {
                                 __hip_atomic_store(&s_quit, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1512,7 +1518,10 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             if (f == GSX_RANK_NONE && !looked && A > GSX_SAT_ALPHA) f = k_cur;     // the list ended at or before rank k_cur
             mine = max(mine, f);
             if (!monotone && __syncthreads_or(f == GSX_RANK_NONE)) {               // a pixel of this tile never gets there: tell everybody now
-                if (threadIdx.x == 0) atomicMax(state + 2, GSX_RANK_NONE);
+                if (threadIdx.x == 0) {
+                    atomicMax(state + 2, GSX_RANK_NONE);
+                    __hip_atomic_store(bar_never, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // (behind the maximum: who sees this sees that)
+                }
                 quit = true;
             }
         }
@@ -1532,10 +1541,12 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             if (!quit) {
                 atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
                 // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
-                __hip_atomic_fetch_add(state + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(bar_arrivals, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t target = round * n_blocks;
-                while (__hip_atomic_load(state + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target &&
-                       __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != GSX_RANK_NONE) __builtin_amdgcn_s_sleep(8);
+                while (__hip_atomic_load(bar_arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                       __hip_atomic_load(bar_never, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);            // (~7 us between looks)
+                }
             }
             s_k = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1546,7 +1557,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         if (k_new == GSX_RANK_NONE || k_new == k_cur) break;      // never / a fixpoint (every workgroup reads the same value: uniform)
         k_cur = k_new;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = result;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = result; state[3] = __hip_atomic_load(bar_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1920,7 +1931,7 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state, chunk_base,
-                                                         max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr);
+                                                         max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr, work);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
