@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     // A trained bench scene's walk takes 1.5 of a splat's 4 quadrants on average.  Without masks (deep views) every splat is taken.
     __shared__ unsigned long long s_sets[4][4];
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_k, s_quit;
+    __shared__ uint32_t s_k;
     // Checkpoints of a non-monotone view's rounds: where the walk of the workgroup's j-th tile stood at the START of the last batch it
     // took (position in the list, A of every pixel there).  k only grows, and every instance in front of that batch has a rank below
     // the round's new k (the batch was walked because a pixel found its rank in it, or met the first rank above the old k in it), so
@@ -1473,8 +1473,14 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
                 if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
-                uint32_t seen = 0u;                           // thread 0: the word as loaded one look ago (the load's latency runs under 32 splats)
-                if (!monotone && threadIdx.x == 0) { seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_quit = seen; }
+                // has somebody found a pixel that never gets there?  One look per EIGHT batches and workgroup: loads of one address from all
+                // over the chip are served one after the other like atomics (~60 ns each), so 512 workgroups looking once per batch (and
+                // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
+                // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
+                uint32_t seen = 0u;
+                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 7u) == 0u) {
+                    seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1484,19 +1490,11 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 __syncthreads();
                 fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
-                uint32_t visited = 0u;
-                bool leave = false;
+                const bool leave = false;
                 for (int seg = 0; seg < 4 && !leave; seg++) {
                     for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        if (!monotone && (++visited & 127u) == 0u) {     // every 128 splats: has somebody found a pixel that never gets there?
-                            if (threadIdx.x == 0) {
-                                __hip_atomic_store(&s_quit, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            if (__hip_atomic_load(&s_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GSX_RANK_NONE) { leave = true; break; }   // (each wave for itself)
-                        }
                         const uint32_t r = s_rank[j];
                         const float4 a = s_a[j], b = s_b[j];
                         const float dx = gx - a.x, dy = gy - a.y;
@@ -1511,7 +1509,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
                 // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)
-                if (!monotone && __syncthreads_or(threadIdx.x == 0 && (seen == GSX_RANK_NONE || s_quit == GSX_RANK_NONE))) { quit = true; break; }
+                if (!monotone && __syncthreads_or(threadIdx.x == 0 && seen == GSX_RANK_NONE)) { quit = true; break; }
                 if (all_found) break;
             }
             if (quit) break;

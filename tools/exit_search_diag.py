@@ -26,4 +26,7 @@ for v in (0, 5, 10, 15, 20, 40):
         outs, vs, extra = R.forward_view(P, poses[v], H, W)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     st = vs.state.cpu().numpy().astype(np.uint32).ravel()
+    rg = vs.ranges.cpu().numpy().astype(np.int64).reshape(-1, 2)
+    ln = np.sort(rg[:, 1] - rg[:, 0])[::-1]
+    print("         tile list lengths: max", ln[:5].tolist(), "median", int(np.median(ln)), "tiles > 8k:", int((ln > 8192).sum()), "> 2k:", int((ln > 2048).sum()))
     print(f"view {v:2d}: forward {dt*1e3:7.3f} ms  exit rank {int(st[0]):>10d}  flags {int(st[1])}  max {int(st[2]):>10d}  arrivals {int(st[3])} (rounds {int(st[3]) / 512:.1f})  D {vs.D}")
