@@ -1388,7 +1388,8 @@ constexpr int kSatBlocks = 512;           // workgroups that take part in the ro
 __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
-    const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work)
+    const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work,
+    const uint32_t* __restrict__ list)
 {
     // The grid barrier of the rounds lives in the work counters' line (two words nothing else uses between the passes: arrivals, and a
     // copy of "some pixel never saturates"), NOT next to state[2]: the workgroups that still walk look at state[2] every 128 splats,
@@ -1425,6 +1426,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     // (zeroed by pass 0) and is done.  Otherwise the rounds below, on the first kSatBlocks workgroups only.
     const bool monotone = (flags & 2u) == 0u;
     const bool use_masks = masks != nullptr && chunk_base[n_tiles] < kDeepChunks;
+    const bool by_list = list != nullptr && chunk_base[n_tiles] < kDeepChunks && work[kWorkNonEmpty] == (uint32_t)n_tiles;
     const uint32_t ch_mask = chunk_base[n_tiles + 1] - 1u;              // chunk size (64, 128 or 256) - 1
     const int ch_shift = 31 - __builtin_clz(chunk_base[n_tiles + 1]);
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -1447,7 +1449,11 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // (a stride walk over the tiles: with the identity map the first tiles of all workgroups are the image's top rows -- on
             // the bench orbit the dense band itself, so that the first sparse tile, the one with the pixel that never saturates,
             // only came up in the second round of tiles, 60 us into the search)
-            const int tile = (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles);
+            // A shallow view that got here has no empty tile, so the combine pass's list holds every tile, the deep ones (more than
+            // twelve chunks) first: dealt out in that order every workgroup gets at most one of up to kSatBlocks deep tiles -- the
+            // stride walk gave some workgroup three of a trained bench scene's 180 lists of 8-19 k splats, and the search is as long
+            // as the longest workgroup's walks.
+            const int tile = by_list ? (int)list[ti] : (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles);
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
             int x, y; pix_xy(wave, lane, tile % tw, tile / tw, x, y);      // (wave = quadrant)
             const bool inside = x < W && y < H;
@@ -1929,7 +1935,8 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     // the three launches below only have work on a saturated view (the reference's global exit): small grids, grid stride
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state, chunk_base,
-                                                         max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr, work);
+                                                         max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr, work,
+                                                         max_chunks > 0 ? order_tab : nullptr);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
