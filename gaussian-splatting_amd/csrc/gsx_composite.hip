@@ -1442,9 +1442,12 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // the end in ONE workgroup (17 k splats, 1.4 ms on the bench scene after 1200 steps: the trainer step had doubled), while
         // a sparse tile at the image's edge answers in microseconds.  Everybody still arrives at the barrier below.
         bool quit = false;
-        int slot = -1;
-        for (int ti = blockIdx.x; ti < n_tiles && !quit; ti += n_blocks) {
-            slot++;
+        // (the workgroup's tiles LAST FIRST: in list order its deep tile comes first, and a view with a pixel that never saturates --
+        // nearly always on a sparse tile -- would have every workgroup a third of a millisecond into a deep list before anybody
+        // found it)
+        const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
+        for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
+            const int ti = (int)blockIdx.x + slot * (int)n_blocks;
             const bool ck = !monotone && slot < kSatCk;
             // (a stride walk over the tiles: with the identity map the first tiles of all workgroups are the image's top rows -- on
             // the bench orbit the dense band itself, so that the first sparse tile, the one with the pixel that never saturates,
@@ -1479,12 +1482,12 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
                 if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
-                // has somebody found a pixel that never gets there?  One look per EIGHT batches and workgroup: loads of one address from all
+                // has somebody found a pixel that never gets there?  One look per FOUR batches and workgroup: loads of one address from all
                 // over the chip are served one after the other like atomics (~60 ns each), so 512 workgroups looking once per batch (and
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
                 uint32_t seen = 0u;
-                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 7u) == 0u) {
+                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 3u) == 0u) {      // (incl. every tile's first batch)
                     seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
