@@ -1487,7 +1487,9 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
                 uint32_t seen = 0u;
-                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 3u) == 0u) {      // (incl. every tile's first batch)
+                // (a list of a batch or two is walked without a look: eight of those per workgroup at the start of the search were a
+                // burst of four thousand looks, a quarter of a millisecond of them one after the other)
+                if (!monotone && threadIdx.x == 0 && end - start0 > 2u * kBlock && (((start - start0) / kBlock) & 3u) == 0u) {
                     seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
