@@ -1446,6 +1446,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // nearly always on a sparse tile -- would have every workgroup a third of a millisecond into a deep list before anybody
         // found it)
         const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
+        uint32_t pending = 0u;               // thread 0: the word as loaded one look ago
         for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
             const int ti = (int)blockIdx.x + slot * (int)n_blocks;
             const bool ck = !monotone && slot < kSatCk;
@@ -1486,11 +1487,11 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 // over the chip are served one after the other like atomics (~60 ns each), so 512 workgroups looking once per batch (and
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
+                // (thread 0 takes the answer of its PREVIOUS look and sends the next one off: the load travels while the batch is walked)
                 uint32_t seen = 0u;
-                // (a list of a batch or two is walked without a look: eight of those per workgroup at the start of the search were a
-                // burst of four thousand looks, a quarter of a millisecond of them one after the other)
-                if (!monotone && threadIdx.x == 0 && end - start0 > 2u * kBlock && (((start - start0) / kBlock) & 3u) == 0u) {
-                    seen = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 3u) == 0u) {      // (incl. every tile's first batch)
+                    seen = pending;
+                    pending = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
 #pragma unroll
