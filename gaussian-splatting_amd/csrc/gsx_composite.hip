@@ -1483,13 +1483,16 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
                 if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
-                // has somebody found a pixel that never gets there?  One look per FOUR batches and workgroup: loads of one address from all
+                // has somebody found a pixel that never gets there?  A look per batch at a list's head, then one per EIGHT batches and workgroup: loads of one address from all
                 // over the chip are served one after the other like atomics (~60 ns each), so 512 workgroups looking once per batch (and
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
                 // (thread 0 takes the answer of its PREVIOUS look and sends the next one off: the load travels while the batch is walked)
                 uint32_t seen = 0u;
-                if (!monotone && threadIdx.x == 0 && (((start - start0) / kBlock) & 3u) == 0u) {      // (incl. every tile's first batch)
+                // (every one of a tile's first four batches -- where a view with a pixel that never saturates is found out, and every
+                // workgroup should leave within a batch or two -- then every eighth)
+                const uint32_t bno = (start - start0) / kBlock;
+                if (!monotone && threadIdx.x == 0 && (bno < 4u || (bno & 7u) == 0u)) {
                     seen = pending;
                     pending = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
