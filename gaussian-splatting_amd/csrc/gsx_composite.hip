@@ -1457,7 +1457,12 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // twelve chunks) first: dealt out in that order every workgroup gets at most one of up to kSatBlocks deep tiles -- the
             // stride walk gave some workgroup three of a trained bench scene's 180 lists of 8-19 k splats, and the search is as long
             // as the longest workgroup's walks.
-            const int tile = by_list ? (int)list[ti] : (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles);
+            // (the rest of the list in a stride walk: in list order all workgroups would be on the same eight rows of tiles at a time,
+            // and the sparse tile whose pixel never saturates -- which ends the search for everybody -- may be anywhere)
+            const uint32_t n_big = by_list ? min(work[kWorkBig], (uint32_t)n_tiles) : 0u;
+            const int tile = !by_list ? (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles)
+                           : (uint32_t)ti < n_big ? (int)list[ti]
+                           : (int)list[n_big + chunk_of_block((uint32_t)ti - n_big, (uint32_t)n_tiles - n_big)];
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
             int x, y; pix_xy(wave, lane, tile % tw, tile / tw, x, y);      // (wave = quadrant)
             const bool inside = x < W && y < H;
