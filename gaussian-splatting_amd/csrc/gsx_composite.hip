@@ -635,8 +635,6 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 }
 
 constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (written by the last list block of the chunk pass)
-constexpr int kWorkCand = 13;             // work[13]: candidates for "never saturated" left by the combine pass (tile_combine_par_kernel), cleared with the counters
-constexpr int kSatCand = 64;              // ... at most this many, in the first words of pass 1's class-0 list
 constexpr int kWorkBig = 6;               // work[6]: how many of them have more than kParSmall chunks (they come first in the list)
 constexpr int kListTiles = 16;            // tiles per list block
 constexpr int kParSmall = 12;             // = ParShape::U: a tile of up to this many chunks is one GROUP's work in the combine pass
@@ -1332,19 +1330,6 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
         const uint32_t raise = (__syncthreads_or(unsat) ? 1u : 0u) | (any_nonmono ? 2u : 0u);
         if (raise && threadIdx.x == 0 &&
             (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & raise) != raise) atomicOr(state + 1, raise);
-        // Where the exact search (F3) should look first: a pixel of a non-monotone tile that ends unsaturated does not veto (above),
-        // but it is the only kind that can turn out never to have been saturated -- which ends the search for every workgroup, after
-        // ONE walk of that tile's list.  The first kSatCand waves that hold such a pixel leave their tile's number behind the work
-        // counters (in pass 1's lists, which nothing reads before the search is over); a wave looks at the count before it adds to
-        // it, so a view with such pixels everywhere pays for some sixty same-address atomics, not for one per tile.
-        {
-            const bool cand = (SOLO ? valid : grp == 0) && inside && (A <= GSX_SAT_ALPHA - 1e-5f) && tile_nonmono;
-            if (max_chunks >= (uint32_t)kSatCand && __builtin_amdgcn_ballot_w64(cand) != 0ull && lane == 0u &&
-                __hip_atomic_load(work + kWorkCand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)kSatCand) {
-                const uint32_t at = atomicAdd(work + kWorkCand, 1u);
-                if (at < (uint32_t)kSatCand) work_list(work, true, 0, max_chunks)[at] = (uint32_t)tile;
-            }
-        }
     }
     if constexpr (SOLO) {
         if (need_bwd) {
@@ -1404,7 +1389,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
     const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work,
-    const uint32_t* __restrict__ list, uint32_t max_chunks)
+    const uint32_t* __restrict__ list)
 {
     // The grid barrier of the rounds lives in the work counters' line (two words nothing else uses between the passes: arrivals, and a
     // copy of "some pixel never saturates"), NOT next to state[2]: the workgroups that still walk look at state[2] every 128 splats,
@@ -1447,8 +1432,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
     const uint32_t n_blocks = monotone ? gridDim.x : min(gridDim.x, (uint32_t)kSatBlocks);
     if (blockIdx.x >= n_blocks) return;
-    // (the combine pass of a shallow view counts its candidates in work[kWorkCand]; a deep view's leaves the word at zero)
-    const uint32_t n_cand = (!monotone && max_chunks >= (uint32_t)kSatCand) ? min(work[kWorkCand], (uint32_t)kSatCand) : 0u;
     uint32_t k_cur = 0u, result;
     for (uint32_t round = 1u; ; round++) {
         uint32_t mine = 0u;                  // max of f_p(k_cur) over this thread's pixels (GSX_RANK_NONE = never: the largest value)
@@ -1464,13 +1447,9 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // found it)
         const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
         uint32_t pending = 0u;               // thread 0: the word as loaded one look ago
-        // (in front of them, in the first round: one of the tiles the combine pass has named as candidates for a pixel that never
-        // saturates -- the first kSatCand workgroups take one each; if it is one, the search is over after that one walk)
-        const bool extra = round == 1u && blockIdx.x < n_cand;
-        for (int slot = extra ? n_mine : n_mine - 1; slot >= 0 && !quit; slot--) {
-            const bool is_cand = slot == n_mine;
+        for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
             const int ti = (int)blockIdx.x + slot * (int)n_blocks;
-            const bool ck = !monotone && !is_cand && slot < kSatCk;
+            const bool ck = !monotone && slot < kSatCk;
             // (a stride walk over the tiles: with the identity map the first tiles of all workgroups are the image's top rows -- on
             // the bench orbit the dense band itself, so that the first sparse tile, the one with the pixel that never saturates,
             // only came up in the second round of tiles, 60 us into the search)
@@ -1481,8 +1460,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // (the rest of the list in a stride walk: in list order all workgroups would be on the same eight rows of tiles at a time,
             // and the sparse tile whose pixel never saturates -- which ends the search for everybody -- may be anywhere)
             const uint32_t n_big = by_list ? min(work[kWorkBig], (uint32_t)n_tiles) : 0u;
-            const int tile = is_cand ? (int)min(work_list(work, true, 0, max_chunks)[blockIdx.x], (uint32_t)n_tiles - 1u)
-                           : !by_list ? (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles)
+            const int tile = !by_list ? (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles)
                            : (uint32_t)ti < n_big ? (int)list[ti]
                            : (int)list[n_big + chunk_of_block((uint32_t)ti - n_big, (uint32_t)n_tiles - n_big)];
             const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
@@ -1972,7 +1950,7 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state, chunk_base,
                                                          max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr, work,
-                                                         max_chunks > 0 ? order_tab : nullptr, (uint32_t)max_chunks);
+                                                         max_chunks > 0 ? order_tab : nullptr);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
