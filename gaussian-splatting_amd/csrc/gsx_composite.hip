@@ -635,6 +635,20 @@ __global__ __launch_bounds__(64) void chunk_fwd_kernel(
 }
 
 constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles (written by the last list block of the chunk pass)
+// The exit search's signal words (saturation_rank_kernel): one 64-bit word {round, rank} per copy, the copies kSigStride words apart
+// in pass 1's work lists (which nothing reads before the search is over); a view too small for that has the one copy in work[14..15].
+// The combine pass in front of the search zeroes them.  work[13]: the search's barrier arrivals.
+constexpr int kWorkArrivals = 13;
+constexpr uint32_t kSigCopies = 64u, kSigStride = 32u;
+__device__ __forceinline__ uint32_t sig_copies(uint32_t max_chunks)
+{
+    return max_chunks >= 256u ? kSigCopies : min(kSigCopies, 2u * (uint32_t)kWorkClasses * max_chunks / kSigStride);
+}
+__device__ __forceinline__ unsigned long long* sig_word(uint32_t* work, uint32_t max_chunks, uint32_t c)
+{
+    return sig_copies(max_chunks) ? reinterpret_cast<unsigned long long*>(work + 16 + (size_t)2 * kWorkClasses * max_chunks + (size_t)c * kSigStride)
+                                  : reinterpret_cast<unsigned long long*>(work + 14);
+}
 constexpr int kWorkBig = 6;               // work[6]: how many of them have more than kParSmall chunks (they come first in the list)
 constexpr int kListTiles = 16;            // tiles per list block
 constexpr int kParSmall = 12;             // = ParShape::U: a tile of up to this many chunks is one GROUP's work in the combine pass
@@ -1116,6 +1130,9 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     // per group and pixel: what the group's chunks add (colour 3, depth with DEPTH) and let through (mantissa, exponent)
     __shared__ float s_agg[G][NA][kPixPerTile];
     __shared__ uint8_t s_dark[kParBatch][4];
+    // (the exit search's signal words, for shallow and deep views alike: this launch is in front of every search)
+    if (blockIdx.x == 0 && threadIdx.x < max(sig_copies(max_chunks), 1u))
+        __hip_atomic_store(sig_word(work, max_chunks, threadIdx.x), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (chunk_base[n_tiles] >= kDeepChunks) return;                                  // the deep instantiation's view
     const uint32_t n_held = work[kWorkNonEmpty];
     // alpha = 0 on an empty tile is "not saturated": it vetoes the global exit (one workgroup says so for all of them; a
@@ -1389,14 +1406,16 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
     const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work,
-    const uint32_t* __restrict__ list)
+    const uint32_t* __restrict__ list, uint32_t max_chunks)
 {
     // The grid barrier of the rounds lives in the work counters' line (two words nothing else uses between the passes: arrivals, and a
     // copy of "some pixel never saturates"), NOT next to state[2]: the workgroups that still walk look at state[2] every 128 splats,
     // and with up to 511 waiting workgroups polling the same 16 bytes each of those looks took tens of microseconds -- a trained bench
     // scene's search ran at a microsecond per splat (5 ms a view) whatever its walk cost.
-    uint32_t* const bar_arrivals = work + 14;
-    uint32_t* const bar_never = work + 15;
+    uint32_t* const bar_arrivals = work + kWorkArrivals;
+    const uint32_t n_sig = max(sig_copies(max_chunks), 1u);
+    unsigned long long* const my_sig = sig_word(work, max_chunks, blockIdx.x % n_sig);
+    constexpr unsigned long long kSigNever = ~0ull;
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
     // which of the batch's 256 splats reach which 8x8 quadrant of the tile: [staging wave][quadrant] -> 64 bits.  Wave w walks
@@ -1446,7 +1465,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // nearly always on a sparse tile -- would have every workgroup a third of a millisecond into a deep list before anybody
         // found it)
         const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
-        uint32_t pending = 0u;               // thread 0: the word as loaded one look ago
         for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
             const int ti = (int)blockIdx.x + slot * (int)n_blocks;
             const bool ck = !monotone && slot < kSatCk;
@@ -1493,14 +1511,8 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
                 // (thread 0 takes the answer of its PREVIOUS look and sends the next one off: the load travels while the batch is walked)
-                uint32_t seen = 0u;
-                // (every one of a tile's first four batches -- where a view with a pixel that never saturates is found out, and every
-                // workgroup should leave within a batch or two -- then every eighth)
-                const uint32_t bno = (start - start0) / kBlock;
-                if (!monotone && threadIdx.x == 0 && (bno < 4u || (bno & 7u) == 0u)) {
-                    seen = pending;
-                    pending = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                unsigned long long seen = 0ull;
+                if (!monotone && threadIdx.x == 0) seen = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1529,17 +1541,16 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
                 // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)
-                if (!monotone && __syncthreads_or(threadIdx.x == 0 && seen == GSX_RANK_NONE)) { quit = true; break; }
+                if (!monotone && __syncthreads_or(threadIdx.x == 0 && seen == kSigNever)) { quit = true; break; }
                 if (all_found) break;
             }
             if (quit) break;
             if (f == GSX_RANK_NONE && !looked && A > GSX_SAT_ALPHA) f = k_cur;     // the list ended at or before rank k_cur
             mine = max(mine, f);
             if (!monotone && __syncthreads_or(f == GSX_RANK_NONE)) {               // a pixel of this tile never gets there: tell everybody now
-                if (threadIdx.x == 0) {
-                    atomicMax(state + 2, GSX_RANK_NONE);
-                    __hip_atomic_store(bar_never, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // (behind the maximum: who sees this sees that)
-                }
+                if (threadIdx.x == 0) atomicMax(state + 2, GSX_RANK_NONE);
+                // (a maximum, like the round's word below: the largest value stays whichever lands last)
+                if (threadIdx.x < n_sig) __hip_atomic_fetch_max(sig_word(work, max_chunks, threadIdx.x), kSigNever, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 quit = true;
             }
         }
@@ -1556,17 +1567,28 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // A workgroup that has seen (or raised) "never" neither adds to the maximum nor arrives: the search is over, and whoever
             // waits at the barrier leaves it on the same word.  (512 arrivals + 512 maxima on one cache line are ~65 us of
             // serialised atomics -- what was left of the search on a trained bench scene once the walks ended early.)
+            uint32_t k_seen = GSX_RANK_NONE;
             if (!quit) {
                 atomicMax(state + 2, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
-                // grid barrier: arrive (release: the maximum above is out), wait for everybody (acquire), read the round's maximum
-                __hip_atomic_fetch_add(bar_arrivals, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // grid barrier: arrive (release: the maximum above is out; acquire: the last to arrive sees everybody's).  The last one
+                // reads the round's maximum and hands it to everybody through the signal words, {round, maximum} in every copy; the
+                // others wait on THEIR copy (eight workgroups to a line: a look is a microsecond, not the tens of microseconds that
+                // five hundred waiting workgroups looking at one word cost each other -- and the workgroups still walking with them).
                 const uint32_t target = round * n_blocks;
-                while (__hip_atomic_load(bar_arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target &&
-                       __hip_atomic_load(bar_never, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);            // (~7 us between looks)
+                if (__hip_atomic_fetch_add(bar_arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == target) {
+                    const unsigned long long word = ((unsigned long long)round << 32) |
+                                                    __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t c = 0; c < n_sig; c++)
+                        __hip_atomic_fetch_max(sig_word(work, max_chunks, c), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                for (;;) {
+                    const unsigned long long w = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w == kSigNever) break;
+                    if ((uint32_t)(w >> 32) == round) { k_seen = (uint32_t)w; break; }
+                    __builtin_amdgcn_s_sleep(32);            // (~1 us between looks)
                 }
             }
-            s_k = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_k = k_seen;
         }
         __syncthreads();
         const uint32_t k_new = s_k;
@@ -1950,7 +1972,7 @@ int gsx::composite_fwd_impl(const float* rec, const uint32_t* ranks_sorted, cons
     const dim3 gc1((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), gt1((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
     saturation_rank_kernel<<<gt1, dim3(kBlock), 0, st>>>(r4, ranks_sorted, ranges, H, W, tw, n_tiles, sx, sy, state, chunk_base,
                                                          max_chunks > 0 ? reinterpret_cast<const uint8_t*>(pay) : nullptr, work,
-                                                         max_chunks > 0 ? order_tab : nullptr);
+                                                         max_chunks > 0 ? order_tab : nullptr, (uint32_t)max_chunks);
     if (max_chunks > 0) {
         if (depth_map) {
             chunk_fwd_kernel<true, true, false><<<gc1, dim3(64), 0, st>>>(r4, ranks_sorted, ranges, chunk_base, n_tiles, (uint32_t)N, H, W, tw, sx, sy, state, chunk_state, meta, work, hdr, pay, order_tab, nullptr);
