@@ -1548,9 +1548,17 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             if (f == GSX_RANK_NONE && !looked && A > GSX_SAT_ALPHA) f = k_cur;     // the list ended at or before rank k_cur
             mine = max(mine, f);
             if (!monotone && __syncthreads_or(f == GSX_RANK_NONE)) {               // a pixel of this tile never gets there: tell everybody now
-                if (threadIdx.x == 0) atomicMax(state + 2, GSX_RANK_NONE);
-                // (a maximum, like the round's word below: the largest value stays whichever lands last)
-                if (threadIdx.x < n_sig) __hip_atomic_fetch_max(sig_word(work, max_chunks, threadIdx.x), kSigNever, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // A trained scene has such pixels on hundreds of tiles, and every workgroup that meets one in its first tile gets here
+                // within the same few microseconds: the first of the workgroups that share a signal word goes on to the running maximum,
+                // the first of those to the other copies -- 8, then 64, then 63 atomics on a line at worst, not 512 on each of 65 lines
+                // (30 us of queueing for every look the workgroups still walking took).  (Maxima, like the rounds' words below: the
+                // largest value stays whichever lands last.)
+                if (threadIdx.x == 0 &&
+                    __hip_atomic_fetch_max(my_sig, kSigNever, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSigNever &&
+                    atomicMax(state + 2, GSX_RANK_NONE) != GSX_RANK_NONE) {
+                    for (uint32_t c = 0; c < n_sig; c++)
+                        __hip_atomic_fetch_max(sig_word(work, max_chunks, c), kSigNever, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 quit = true;
             }
         }
