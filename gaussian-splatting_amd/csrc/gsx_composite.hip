@@ -639,10 +639,10 @@ constexpr int kWorkNonEmpty = 5;          // work[5]: number of non-empty tiles 
 // in pass 1's work lists (which nothing reads before the search is over); a view too small for that has the one copy in work[14..15].
 // The combine pass in front of the search zeroes them.  work[13]: the search's barrier arrivals.
 constexpr int kWorkArrivals = 13;
-constexpr uint32_t kSigCopies = 64u, kSigStride = 32u;
+constexpr uint32_t kSigCopies = 256u, kSigStride = 32u;
 __device__ __forceinline__ uint32_t sig_copies(uint32_t max_chunks)
 {
-    return max_chunks >= 256u ? kSigCopies : min(kSigCopies, 2u * (uint32_t)kWorkClasses * max_chunks / kSigStride);
+    return max_chunks >= 1024u ? kSigCopies : min(kSigCopies, 2u * (uint32_t)kWorkClasses * max_chunks / kSigStride);
 }
 __device__ __forceinline__ unsigned long long* sig_word(uint32_t* work, uint32_t max_chunks, uint32_t c)
 {
@@ -1414,7 +1414,8 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     // scene's search ran at a microsecond per splat (5 ms a view) whatever its walk cost.
     uint32_t* const bar_arrivals = work + kWorkArrivals;
     const uint32_t n_sig = max(sig_copies(max_chunks), 1u);
-    unsigned long long* const my_sig = sig_word(work, max_chunks, blockIdx.x % n_sig);
+    // (a copy per wave: every wave looks for itself while it walks, below)
+    unsigned long long* const my_sig = sig_word(work, max_chunks, (blockIdx.x * 4u + (threadIdx.x >> 6)) % n_sig);
     constexpr unsigned long long kSigNever = ~0ull;
     __shared__ float4 s_a[kBlock], s_b[kBlock];
     __shared__ uint32_t s_rank[kBlock];
@@ -1465,6 +1466,8 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         // nearly always on a sparse tile -- would have every workgroup a third of a millisecond into a deep list before anybody
         // found it)
         const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
+        unsigned long long pending = 0ull;   // the wave's signal word as loaded one look ago
+        bool leave = false;
         for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
             const int ti = (int)blockIdx.x + slot * (int)n_blocks;
             const bool ck = !monotone && slot < kSatCk;
@@ -1511,8 +1514,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
                 // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
                 // (thread 0 takes the answer of its PREVIOUS look and sends the next one off: the load travels while the batch is walked)
-                unsigned long long seen = 0ull;
-                if (!monotone && threadIdx.x == 0) seen = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1522,8 +1524,15 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 __syncthreads();
                 fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
-                const bool leave = false;
+                // Has somebody found a pixel that never gets there?  Every wave looks at its copy of the signal word four times a batch
+                // (all lanes load the one address: one request; the answer is taken at the NEXT look, so nobody waits for it) and
+                // leaves the batch where it stands: a batch of 256 splats is up to 12 us of walking, and the search of a view that
+                // has no exit is as long as the slowest workgroup takes to notice.
                 for (int seg = 0; seg < 4 && !leave; seg++) {
+                    if (!monotone) {
+                        if (pending == kSigNever) { leave = true; break; }
+                        pending = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
@@ -1541,7 +1550,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
                 // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)
-                if (!monotone && __syncthreads_or(threadIdx.x == 0 && seen == kSigNever)) { quit = true; break; }
+                if (!monotone && __syncthreads_or(leave)) { quit = true; break; }
                 if (all_found) break;
             }
             if (quit) break;
