@@ -1398,7 +1398,17 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
 // workgroup arrives at every barrier, and the rounds end because k grows until it stands or some pixel reports "never");
 // a view without a non-monotone splat (state[1] bit 1 clear: the combine pass raises it from the chunks' flags) takes the
 // one pass it always took, on the whole grid, without a barrier.  state[2] = the running maximum (monotone: no reset between
-// rounds), zeroed with state[0..1] by pass 0; the barrier's arrivals count in the work counters' line (below), state[3] gets a copy at the end.
+// rounds), zeroed with state[0..1] by pass 0; state[3] gets a copy of the barrier's arrivals at the end.
+// What the rounds cost on a trained scene (round 3; profiles/r3_soak_3000_steps.txt): NOT the walks.  Loads and atomics of one
+// address from all over the chip are served one after the other, some 60 ns each, so every word that 512 workgroups look at
+// costs each of them 30 us a look -- the running maximum, the barrier's counter, a "search is over" flag; with a look per
+// batch of 256 splats a view's search took 5 ms where its walks are a tenth of that.  Hence: (i) what the workgroups wait
+// for and look at while they walk is a SIGNAL WORD {round, rank}, kept in up to 256 copies on lines of their own (eight
+// waves to a copy); the last workgroup to arrive at a barrier reads the maximum and writes the round's word to every copy,
+// the first workgroup to find a pixel that never saturates writes all-ones; (ii) a workgroup keeps, per tile, where its walk
+// stood (checkpoints, below), so the rounds together are one pass over the lists; (iii) the tiles are dealt from the combine
+// pass's list, deep ones first, one per workgroup, and a workgroup takes its sparse tiles first; (iv) a wave walks one 8x8
+// quadrant and only the splats whose mask byte (the chunk pass's) reaches it.
 // ------------------------------------------------------------------------------------------
 constexpr int kSatBlocks = 512;           // workgroups that take part in the rounds of a non-monotone view: a quarter of what the chip holds
                                           // resident (8 of these per CU), so that up to four streams' searches can spin side by side
@@ -1408,10 +1418,8 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work,
     const uint32_t* __restrict__ list, uint32_t max_chunks)
 {
-    // The grid barrier of the rounds lives in the work counters' line (two words nothing else uses between the passes: arrivals, and a
-    // copy of "some pixel never saturates"), NOT next to state[2]: the workgroups that still walk look at state[2] every 128 splats,
-    // and with up to 511 waiting workgroups polling the same 16 bytes each of those looks took tens of microseconds -- a trained bench
-    // scene's search ran at a microsecond per splat (5 ms a view) whatever its walk cost.
+    // The barrier's arrivals count in the work counters' line (a word nothing else uses between the passes), NOT next to state[2];
+    // nobody waits on it: the waiting is on the signal words.
     uint32_t* const bar_arrivals = work + kWorkArrivals;
     const uint32_t n_sig = max(sig_copies(max_chunks), 1u);
     // (a copy per wave: every wave looks for itself while it walks, below)
@@ -1456,11 +1464,10 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     for (uint32_t round = 1u; ; round++) {
         uint32_t mine = 0u;                  // max of f_p(k_cur) over this thread's pixels (GSX_RANK_NONE = never: the largest value)
         // A pixel that is never saturated from k_cur on settles the search ("no exit"), whatever the other tiles say.  In the rounds of
-        // a non-monotone view the workgroup that finds one says so at once (the running maximum goes to GSX_RANK_NONE) and every
-        // workgroup looks at that word every 32 splats (thread 0 loads it, one look ahead, and passes it on through LDS): a trained scene -- a few screen-sized splats put something on
-        // every tile, opacities have drifted out of [0, 1] everywhere, nothing vetoes -- otherwise walks its deepest tile list to
-        // the end in ONE workgroup (17 k splats, 1.4 ms on the bench scene after 1200 steps: the trainer step had doubled), while
-        // a sparse tile at the image's edge answers in microseconds.  Everybody still arrives at the barrier below.
+        // a non-monotone view the workgroup that finds one says so at once (signal words, below) and every wave looks at its copy four
+        // times a batch: a trained scene -- a few screen-sized splats put something on every tile, opacities have drifted out of
+        // [0, 1] everywhere, nothing vetoes -- otherwise walks its deepest tile list to the end in ONE workgroup (17 k splats, 1.4 ms
+        // on the bench scene after 1200 steps), while a sparse tile at the image's edge answers in microseconds.
         bool quit = false;
         // (the workgroup's tiles LAST FIRST: in list order its deep tile comes first, and a view with a pixel that never saturates --
         // nearly always on a sparse tile -- would have every workgroup a third of a millisecond into a deep list before anybody
@@ -1509,12 +1516,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
                 if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
-                // has somebody found a pixel that never gets there?  A look per batch at a list's head, then one per EIGHT batches and workgroup: loads of one address from all
-                // over the chip are served one after the other like atomics (~60 ns each), so 512 workgroups looking once per batch (and
-                // once per 32 splats inside it) each waited ~25 us per batch for the answer -- the search of a trained bench scene ran at
-                // 100 ns per list position whatever its walk cost (5 ms a view; the walks themselves are a tenth of that)
-                // (thread 0 takes the answer of its PREVIOUS look and sends the next one off: the load travels while the batch is walked)
-
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1549,7 +1550,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                 // (the batch went past rank k_cur without this quadrant meeting a splat behind it: A is the state AT k_cur)
                 if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                 const bool all_found = __syncthreads_and(f != GSX_RANK_NONE);      // (also the barrier before the next batch is staged)
-                // (the workgroup's verdict is thread 0's: the waves may have left the loop above at different splats)
                 if (!monotone && __syncthreads_or(leave)) { quit = true; break; }
                 if (all_found) break;
             }
@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             if (!monotone && __syncthreads_or(f == GSX_RANK_NONE)) {               // a pixel of this tile never gets there: tell everybody now
                 // A trained scene has such pixels on hundreds of tiles, and every workgroup that meets one in its first tile gets here
                 // within the same few microseconds: the first of the workgroups that share a signal word goes on to the running maximum,
-                // the first of those to the other copies -- 8, then 64, then 63 atomics on a line at worst, not 512 on each of 65 lines
+                // the first of those to all the copies -- 8, then 64 atomics on a line at worst, then one per copy, not 512 on every line
                 // (30 us of queueing for every look the workgroups still walking took).  (Maxima, like the rounds' words below: the
                 // largest value stays whichever lands last.)
                 if (threadIdx.x == 0 &&
