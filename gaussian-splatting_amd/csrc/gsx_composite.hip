@@ -1534,28 +1534,17 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                         if (pending == kSigNever) { leave = true; break; }
                         pending = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    // Four splats a step: their alphas do not depend on each other (LDS reads, the quadratic form, exp2 -- some hundred
-                    // cycles of latency that a wave with one neighbour on its SIMD cannot hide otherwise), only A's recurrence does.
                     for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
-                        bool ok[4]; uint32_t r[4]; float am[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            ok[u] = todo != 0ull;                          // (wave-uniform: the sets are)
-                            const uint32_t j = (uint32_t)seg * 64u + (ok[u] ? (uint32_t)__builtin_ctzll(todo) : 0u);
-                            todo &= todo - 1ull;
-                            r[u] = s_rank[j];
-                            const float4 a = s_a[j], b = s_b[j];
-                            const float dx = gx - a.x, dy = gy - a.y;
-                            const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                            am[u] = b.y * __builtin_amdgcn_exp2f(q);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            if (!ok[u]) break;
-                            if (r[u] > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
-                            A = A + (1.0f - A) * am[u];
-                            if (f == GSX_RANK_NONE && r[u] >= k_cur && A > GSX_SAT_ALPHA) f = r[u];
-                        }
+                        const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const uint32_t r = s_rank[j];
+                        const float4 a = s_a[j], b = s_b[j];
+                        const float dx = gx - a.x, dy = gy - a.y;
+                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                        const float am = b.y * __builtin_amdgcn_exp2f(q);
+                        if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
+                        A = A + (1.0f - A) * am;
+                        if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
                     }
                 }
                 // (the batch went past rank k_cur without this quadrant meeting a splat behind it: A is the state AT k_cur)
