@@ -1131,8 +1131,7 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
     __shared__ float s_agg[G][NA][kPixPerTile];
     __shared__ uint8_t s_dark[kParBatch][4];
     // (the exit search's signal words, for shallow and deep views alike: this launch is in front of every search)
-    if (blockIdx.x == 0 && threadIdx.x < max(sig_copies(max_chunks), 1u))
-        __hip_atomic_store(sig_word(work, max_chunks, threadIdx.x), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && threadIdx.x < max(sig_copies(max_chunks), 1u)) *sig_word(work, max_chunks, threadIdx.x) = 0ull;
     if (chunk_base[n_tiles] >= kDeepChunks) return;                                  // the deep instantiation's view
     const uint32_t n_held = work[kWorkNonEmpty];
     // alpha = 0 on an empty tile is "not saturated": it vetoes the global exit (one workgroup says so for all of them; a
