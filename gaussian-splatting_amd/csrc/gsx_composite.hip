@@ -1431,6 +1431,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     // its chunks' payload words); what they drop is what the footprint cut drops from the tile lists themselves: pairs below the cut.
     // A trained bench scene's walk takes 1.5 of a splat's 4 quadrants on average.  Without masks (deep views) every splat is taken.
     __shared__ unsigned long long s_sets[4][4];
+    __shared__ unsigned long long s_below[4];         // [staging wave] -> which of its 64 splats have a rank below the round's k (a prefix: the lists are in rank order)
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_k;
     // Checkpoints of a non-monotone view's rounds: where the walk of the workgroup's j-th tile stood at the START of the last batch it
@@ -1521,6 +1522,10 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     const unsigned long long bset = __builtin_amdgcn_ballot_w64(((nm >> k) & 1u) != 0u);
                     if (lane == 0) s_sets[wave][k] = bset;
                 }
+                {
+                    const unsigned long long bel = __builtin_amdgcn_ballot_w64(start + threadIdx.x < end && nr < k_cur);
+                    if (lane == 0) s_below[wave] = bel;
+                }
                 __syncthreads();
                 fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
@@ -1533,7 +1538,21 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                         if (pending == kSigNever) { leave = true; break; }
                         pending = __hip_atomic_load(my_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    for (unsigned long long todo = s_sets[seg][wave]; todo != 0ull; ) {
+                    // A splat with a rank below k only moves A: nothing is looked at or found in front of k.  From the second round on
+                    // that is most of what a deep tile walks (from where the last round stood up to the new k), at half the
+                    // instructions of the full step -- and a wave that has its SIMD nearly to itself issues one instruction per
+                    // ~5 cycles whatever they depend on, so the instruction count is the walk's time.
+                    const unsigned long long set = s_sets[seg][wave], bel = s_below[seg];
+                    for (unsigned long long todo = set & bel; todo != 0ull; ) {
+                        const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float4 a = s_a[j], b = s_b[j];
+                        const float dx = gx - a.x, dy = gy - a.y;
+                        const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
+                        const float am = b.y * __builtin_amdgcn_exp2f(q);
+                        A = A + (1.0f - A) * am;
+                    }
+                    for (unsigned long long todo = set & ~bel; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
                         const uint32_t r = s_rank[j];
