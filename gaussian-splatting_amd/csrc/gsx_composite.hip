@@ -1542,13 +1542,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     // that is most of what a deep tile walks (from where the last round stood up to the new k), at half the
                     // instructions of the full step -- and a wave that has its SIMD nearly to itself issues one instruction per
                     // ~5 cycles whatever they depend on, so the instruction count is the walk's time.
-                    // (the sets are the same in every lane: in scalar registers the loops' bit scans are scalar instructions, not nine
-                    // vector ones per splat)
-                    auto uni = [](unsigned long long v) {
-                        return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((uint32_t)v);
-                    };
-                    const unsigned long long set = uni(s_sets[seg][wave]), bel = uni(s_below[seg]);
+                    const unsigned long long set = s_sets[seg][wave], bel = s_below[seg];
                     for (unsigned long long todo = set & bel; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
