@@ -1407,7 +1407,8 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
 // the first workgroup to find a pixel that never saturates writes all-ones; (ii) a workgroup keeps, per tile, where its walk
 // stood (checkpoints, below), so the rounds together are one pass over the lists; (iii) the tiles are dealt from the combine
 // pass's list, deep ones first, one per workgroup, and a workgroup takes its sparse tiles first; (iv) a wave walks one 8x8
-// quadrant and only the splats whose mask byte (the chunk pass's) reaches it.
+// quadrant and only the splats whose mask byte (the chunk pass's) reaches it; (v) a splat with a rank below the round's k only
+// moves A, in a loop of half the instructions (a wave nearly alone on its SIMD is bound by instruction issue).
 // ------------------------------------------------------------------------------------------
 constexpr int kSatBlocks = 512;           // workgroups that take part in the rounds of a non-monotone view: a quarter of what the chip holds
                                           // resident (8 of these per CU), so that up to four streams' searches can spin side by side
