@@ -1446,10 +1446,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
     static_assert((size_t)kSatCk * kBlock * 4 + 2 * kBlock * 16 + kBlock * 4 + 256 <= 160 * 1024 / 8, "eight searching workgroups per CU");
     __shared__ float s_ck_a[kSatCk][kBlock];
     __shared__ uint32_t s_ck_pos[kSatCk];
-    // ... and the tile's number, range and first chunk, as the first round loaded them: from the second round on a tile's first batch
-    // is fetched while the tile in front of it is walked (most tiles are one batch a round then, and the chain list -> range ->
-    // ranks -> records was half of a tile's 19 us)
-    __shared__ uint32_t s_ck_desc[kSatCk][4];
     const uint32_t flags = state[1];          // (uniform over the grid: written by pass 0's combine launch)
     if (flags & 1u) {                        // some pixel never saturates: no early exit
         if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = GSX_RANK_NONE;
@@ -1480,19 +1476,6 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
         const int n_mine = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)n_blocks + 1 : 0;
         unsigned long long pending = 0ull;   // the wave's signal word as loaded one look ago
         bool leave = false;
-        // the next batch's records travel while this one is walked (rank, then record: two dependent round trips that every batch
-        // of 256 splats used to wait for)
-        uint32_t nr = 0u, nm = 0u; float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
-        auto fetch = [&](uint32_t at, uint32_t f_begin, uint32_t f_end, uint32_t f_chunk0) {
-            const uint32_t i = at + threadIdx.x;
-            nm = 0u;
-            if (i < f_end) {
-                nr = ranks[i]; const float4* R = rec + (size_t)kRecVec * nr; na = R[0]; nb = R[1];
-                const uint32_t rel = i - f_begin;
-                nm = use_masks ? (uint32_t)masks[(size_t)(f_chunk0 + (rel >> ch_shift)) * (64 * 4) + (rel & ch_mask)] : 0xFu;
-            }
-        };
-        bool fetched = false;                // the tile's first batch is on its way already
         for (int slot = n_mine - 1; slot >= 0 && !quit; slot--) {
             const int ti = (int)blockIdx.x + slot * (int)n_blocks;
             const bool ck = !monotone && slot < kSatCk;
@@ -1505,28 +1488,33 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
             // as the longest workgroup's walks.
             // (the rest of the list in a stride walk: in list order all workgroups would be on the same eight rows of tiles at a time,
             // and the sparse tile whose pixel never saturates -- which ends the search for everybody -- may be anywhere)
-            int tile; uint32_t begin, end, chunk0;
-            if (ck && round > 1u) {
-                tile = (int)s_ck_desc[slot][0]; begin = s_ck_desc[slot][1]; end = s_ck_desc[slot][2]; chunk0 = s_ck_desc[slot][3];
-            } else {
-                const uint32_t n_big = by_list ? min(work[kWorkBig], (uint32_t)n_tiles) : 0u;
-                tile = !by_list ? (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles)
-                     : (uint32_t)ti < n_big ? (int)list[ti]
-                     : (int)list[n_big + chunk_of_block((uint32_t)ti - n_big, (uint32_t)n_tiles - n_big)];
-                begin = ranges[2*tile]; end = ranges[2*tile+1];
-                chunk0 = chunk_base[tile];
-                if (ck && threadIdx.x == 0) { s_ck_desc[slot][0] = (uint32_t)tile; s_ck_desc[slot][1] = begin; s_ck_desc[slot][2] = end; s_ck_desc[slot][3] = chunk0; }
-            }
+            const uint32_t n_big = by_list ? min(work[kWorkBig], (uint32_t)n_tiles) : 0u;
+            const int tile = !by_list ? (int)chunk_of_block((uint32_t)ti, (uint32_t)n_tiles)
+                           : (uint32_t)ti < n_big ? (int)list[ti]
+                           : (int)list[n_big + chunk_of_block((uint32_t)ti - n_big, (uint32_t)n_tiles - n_big)];
+            const uint32_t begin = ranges[2*tile], end = ranges[2*tile+1];
             int x, y; pix_xy(wave, lane, tile % tw, tile / tw, x, y);      // (wave = quadrant)
             const bool inside = x < W && y < H;
+            const uint32_t chunk0 = chunk_base[tile];
             const float gx = pix_coord(min(x, W - 1), W, stepx), gy = pix_coord(min(y, H - 1), H, stepy);
             float A = 0.f;
             uint32_t f = inside ? GSX_RANK_NONE : k_cur;      // pixels outside the image do not vote
             bool looked = false;                              // has the state AT k_cur been looked at
             uint32_t start0 = begin;
             if (ck && round > 1u && begin < end) { start0 = s_ck_pos[slot]; A = s_ck_a[slot][threadIdx.x]; }       // (own words / read behind barriers)
-            if (!fetched) fetch(start0, begin, end, chunk0);
-            fetched = false;
+            // the next batch's records travel while this one is walked (rank, then record: two dependent round trips that every batch
+            // of 256 splats used to wait for)
+            uint32_t nr = 0u, nm = 0u; float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            auto fetch = [&](uint32_t at) {
+                const uint32_t i = at + threadIdx.x;
+                nm = 0u;
+                if (i < end) {
+                    nr = ranks[i]; const float4* R = rec + (size_t)kRecVec * nr; na = R[0]; nb = R[1];
+                    const uint32_t rel = i - begin;
+                    nm = use_masks ? (uint32_t)masks[(size_t)(chunk0 + (rel >> ch_shift)) * (64 * 4) + (rel & ch_mask)] : 0xFu;
+                }
+            };
+            fetch(start0);
             for (uint32_t start = start0; start < end; start += kBlock) {
                 if (ck) { s_ck_a[slot][threadIdx.x] = A; if (threadIdx.x == 0) s_ck_pos[slot] = start; }
                 if (start + threadIdx.x < end) { s_rank[threadIdx.x] = nr; s_a[threadIdx.x] = na; s_b[threadIdx.x] = nb; }
@@ -1540,12 +1528,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     if (lane == 0) s_below[wave] = bel;
                 }
                 __syncthreads();
-                if (start + kBlock < end) fetch(start + kBlock, begin, end, chunk0);
-                else if (ck && round > 1u && slot >= 1) {              // the tile's last batch: the next tile's first one (slot - 1 < kSatCk too)
-                    const uint32_t b2 = s_ck_desc[slot - 1][1], e2 = s_ck_desc[slot - 1][2];
-                    fetch(b2 < e2 ? s_ck_pos[slot - 1] : b2, b2, e2, s_ck_desc[slot - 1][3]);
-                    fetched = true;
-                } else nm = 0u;
+                fetch(start + kBlock);
                 const uint32_t cnt = min((uint32_t)kBlock, end - start);
                 // Has somebody found a pixel that never gets there?  Every wave looks at its copy of the signal word four times a batch
                 // (all lanes load the one address: one request; the answer is taken at the NEXT look, so nobody waits for it) and
