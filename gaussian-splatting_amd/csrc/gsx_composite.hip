@@ -1544,35 +1544,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     // instructions of the full step -- and a wave that has its SIMD nearly to itself issues one instruction per
                     // ~5 cycles whatever they depend on, so the instruction count is the walk's time.
                     const unsigned long long set = s_sets[seg][wave], bel = s_below[seg];
-                    // (a deep tile's splats reach every quadrant: when none of the segment's splats below k is masked out, they are
-                    // the segment's first n -- a counted loop, four splats a step, no bit scans, the LDS reads of a step issued together)
-                    unsigned long long sparse = set & bel;
-                    if (sparse == bel && bel != 0ull) {
-                        const int n_bel = __builtin_amdgcn_readfirstlane(__popcll(bel));
-                        const float4* pa = s_a + seg * 64; const float4* pb = s_b + seg * 64;
-                        int j = 0;
-                        for (; j + 4 <= n_bel; j += 4) {
-                            float am[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const float4 a = pa[j + u], b = pb[j + u];
-                                const float dx = gx - a.x, dy = gy - a.y;
-                                const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                                am[u] = b.y * __builtin_amdgcn_exp2f(q);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; u++) A = A + (1.0f - A) * am[u];
-                        }
-                        for (; j < n_bel; j++) {
-                            const float4 a = pa[j], b = pb[j];
-                            const float dx = gx - a.x, dy = gy - a.y;
-                            const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
-                            const float am = b.y * __builtin_amdgcn_exp2f(q);
-                            A = A + (1.0f - A) * am;
-                        }
-                        sparse = 0ull;
-                    }
-                    for (unsigned long long todo = sparse; todo != 0ull; ) {
+                    for (unsigned long long todo = set & bel; todo != 0ull; ) {
                         const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
                         const float4 a = s_a[j], b = s_b[j];
