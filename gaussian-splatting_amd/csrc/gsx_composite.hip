@@ -1544,19 +1544,18 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                     // instructions of the full step -- and a wave that has its SIMD nearly to itself issues one instruction per
                     // ~5 cycles whatever they depend on, so the instruction count is the walk's time.
                     const unsigned long long set = s_sets[seg][wave], bel = s_below[seg];
-                    // (the bit scans on 32-bit halves: the sets sit in vector registers, and a 64-bit scan step there is nine
-                    // instructions where a 32-bit one is five)
-                    auto scan = [&](uint32_t bits, uint32_t base, auto&& body) {
-                        while (bits != 0u) { const uint32_t j = base + (uint32_t)__builtin_ctz(bits); bits &= bits - 1u; body(j); }
-                    };
-                    auto below_k = [&](uint32_t j) {
+                    for (unsigned long long todo = set & bel; todo != 0ull; ) {
+                        const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
                         const float4 a = s_a[j], b = s_b[j];
                         const float dx = gx - a.x, dy = gy - a.y;
                         const float q = a.z*dx*dx + a.w*dx*dy + b.x*dy*dy;
                         const float am = b.y * __builtin_amdgcn_exp2f(q);
                         A = A + (1.0f - A) * am;
-                    };
-                    auto from_k = [&](uint32_t j) {
+                    }
+                    for (unsigned long long todo = set & ~bel; todo != 0ull; ) {
+                        const uint32_t j = (uint32_t)seg * 64u + (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
                         const uint32_t r = s_rank[j];
                         const float4 a = s_a[j], b = s_b[j];
                         const float dx = gx - a.x, dy = gy - a.y;
@@ -1565,12 +1564,7 @@ __global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
                         if (r > k_cur && !looked) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
                         A = A + (1.0f - A) * am;
                         if (f == GSX_RANK_NONE && r >= k_cur && A > GSX_SAT_ALPHA) f = r;
-                    };
-                    const unsigned long long lo = set & bel, hi = set & ~bel;
-                    scan((uint32_t)lo, (uint32_t)seg * 64u, below_k);
-                    scan((uint32_t)(lo >> 32), (uint32_t)seg * 64u + 32u, below_k);
-                    scan((uint32_t)hi, (uint32_t)seg * 64u, from_k);
-                    scan((uint32_t)(hi >> 32), (uint32_t)seg * 64u + 32u, from_k);
+                    }
                 }
                 // (the batch went past rank k_cur without this quadrant meeting a splat behind it: A is the state AT k_cur)
                 if (!leave && !looked && s_rank[cnt - 1u] > k_cur) { looked = true; if (f == GSX_RANK_NONE && A > GSX_SAT_ALPHA) f = k_cur; }
