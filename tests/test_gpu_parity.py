@@ -268,6 +268,33 @@ def test_synthetic_vs_oracle(dev, O, case):
         assert rel_err(g[k], go[k]) < tol, k + " (rgb only)"
 
 
+# The exit search's ROUNDS at scale (end of round 3): faint splats with opacities on both sides of zero, so that A goes down as well as
+# up (non-monotone: the fixpoint search, not the one-pass rule), every pixel saturates only after hundreds to thousands of splats and
+# the exit rank lies deep in the lists -- several batches of 256 per tile (checkpoints between rounds, the below-k loop), 512
+# workgroups with two or more tiles each, 256 signal-word copies, and, in the two scenes of mixed scales, the chunk pass's quadrant
+# masks.  The reference-run exit fixtures (tests/golden exit*, exitop*) are 16-40 pixels a side: one or two workgroups.
+EXIT_ROUND_CASES = {
+    "screen_sized_4000_512x512": (4000, 33, 0.3, 0.8, -0.05, 0.15, 512),
+    "mixed_scales_8000_512x512": (8000, 34, 0.05, 0.6, -0.05, 0.2, 512),
+    "mixed_scales_12000_384x384": (12000, 35, 0.03, 0.4, -0.1, 0.4, 384),
+}
+
+
+@pytest.mark.parametrize("case", list(EXIT_ROUND_CASES))
+def test_global_exit_rounds_vs_oracle(dev, O, case):
+    n, seed, s_lo, s_hi, o_lo, o_hi, hw = EXIT_ROUND_CASES[case]
+    params = synth_scene(n, seed, s_lo, s_hi, o_lo=o_lo, o_hi=o_hi)
+    pose = pose_tz(2.0)
+    gp = gpu_pipeline(params, pose, hw, hw, dev)
+    fw = O.forward(params, pose, hw, hw, "tiled")
+    assert (params["opacity"] < 0).any()                                  # a splat that takes A down: the search runs in rounds
+    assert 256 < fw["n_composited"] < n and fw["D"] > (1 << 20)          # the exit fires, deep in the lists; 256-instance chunks
+    assert_integer_products_equal(gp, fw)
+    assert gp["n_composited"] == fw["n_composited"]
+    assert np.abs(gp["rgb"] - fw["rgb"]).max() < RGB_TOL
+    assert np.abs(gp["alpha"] - fw["alpha"]).max() < RGB_TOL
+
+
 @pytest.mark.parametrize("chunk", [64, 128, 256])
 def test_every_chunk_size_vs_oracle(dev, O, chunk):
     """The binning stage cuts small views into shorter compositing chunks (64 / 128 / 256 instances by instance count);
