@@ -1412,7 +1412,9 @@ __global__ __launch_bounds__(kParGroups * kBlock) void tile_combine_par_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kSatBlocks = 512;           // workgroups that take part in the rounds of a non-monotone view: a quarter of what the chip holds
                                           // resident (8 of these per CU), so that up to four streams' searches can spin side by side
-__global__ __launch_bounds__(kBlock) void saturation_rank_kernel(
+// (eight waves per SIMD, i.e. at most 64 VGPRs: with the LDS bound below, eight of these workgroups fit a CU -- what "four searches side
+// by side" needs: 4 x 512 workgroups resident at once, or four searches could each hold a part of the chip and wait for the rest)
+__global__ __launch_bounds__(kBlock, 8) void saturation_rank_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ ranges,
     int H, int W, int tw, int n_tiles, float stepx, float stepy, uint32_t* __restrict__ state,
     const uint32_t* __restrict__ chunk_base, const uint8_t* __restrict__ masks, uint32_t* __restrict__ work,
